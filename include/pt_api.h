@@ -1,0 +1,206 @@
+/*
+ * pt_api.h -- C ABI of libpt_hip.so, the MI355X (gfx950) path-tracing backend.
+ *
+ * Part 1 is the drop-in boundary: the exact symbols the reference's Rust host
+ * binds (src/main.rs:9-32, src/guiding.rs:31-68) and that its wrapper DLL
+ * exports (optix/optix_wrapper.cpp, optix/openpgl_bridge.cpp).  Signatures,
+ * argument meaning and error behaviour are the reference's.
+ *
+ * Part 2 (pt_*) are additions with no counterpart in the reference: render-mode
+ * selection, device-resident / sample-sharded rendering for multi-GPU hosts,
+ * the GPU demosaic and EXR output the reference does on the CPU in Rust, ray
+ * counters and per-kernel timing for measurement, and stage-level entry points
+ * used by the parity tests.
+ *
+ * Conventions: plain pointers and sizes only.  Unless a name says "device",
+ * pointers are host pointers.  All failures of the HIP runtime print to stderr
+ * and abort(), like CU_CHECK/OTK_CHECK in optix_wrapper.cpp:48-69; the int
+ * return value is 0, or -1 for a NULL output pointer (optix_wrapper.cpp:980).
+ * The library is not thread-safe (global singleton renderer, like the
+ * reference: optix_wrapper.cpp:923).
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_EXPORT __attribute__((visibility("default")))
+
+/* ====================================================================== *
+ * Part 1 -- the reference's exported surface                              *
+ * ====================================================================== */
+
+/* optix/optix_wrapper.cpp:1102-1107.  Blocking.  Writes w*h*3 floats (row-major,
+ * top row first, interleaved RGB, linear per-pixel radiance means).  Lazily
+ * (re)creates the renderer when (w,h) changes (1087-1100) and increments the
+ * global frame counter (983), so consecutive calls use different seeds.
+ * noise_threshold == 0 disables adaptive sampling. */
+PT_EXPORT int optix_render_rgb(int w, int h, int spp, int max_depth, float noise_threshold,
+                               int min_adaptive_samples, float* out_rgb);
+
+/* optix/optix_wrapper.cpp:1109-1115.  Same render, writes the w*h Bayer mosaic
+ * (value of the CFA channel at each pixel, clamped >= 0; optix_device.cu:1069).
+ * pattern: 0 RGGB, 1 BGGR, 2 GRBG, 3 GBRG (optix_device.cu:902-912). */
+PT_EXPORT int optix_render_bayer_f32(int w, int h, int spp, int max_depth, float noise_threshold,
+                                     int min_adaptive_samples, int pattern, float* out_raw);
+
+/* optix/optix_wrapper.cpp:1132-1164: pinned host memory. */
+PT_EXPORT void* optix_alloc_host(size_t bytes);
+PT_EXPORT void  optix_free_host(void* ptr);
+/* optix/optix_wrapper.cpp:1116-1124: drain the renderer's streams; no-op without a renderer. */
+PT_EXPORT void  optix_synchronize(void);
+
+/* optix/optix_wrapper.cpp:927-976: explicit context API (exported, unused by the Rust host). */
+PT_EXPORT void* optix_ctx_create(int width, int height);
+PT_EXPORT void  optix_ctx_destroy(void* handle);
+PT_EXPORT void  optix_ctx_set_bayer(void* handle, int pattern);
+PT_EXPORT void  optix_ctx_set_camera(void* handle, float eye_x, float eye_y, float eye_z,
+                                     float look_x, float look_y, float look_z,
+                                     float up_x, float up_y, float up_z, float vfov_deg);
+
+/* optix/openpgl_bridge.h:28-29 and optix/guiding_gpu.h:24-29 == src/guiding.rs:5-28 */
+struct pgl_region { float bmin[3]; float bmax[3]; uint32_t lobe_ofs; uint32_t lobe_num; };
+struct pgl_lobe   { float mu[3]; float kappa; float weight; float rgb[3]; };
+typedef struct TrainSample { float position[3]; float dir_in[3]; float contrib[3]; uint32_t is_delta; } TrainSample;
+
+/* optix/optix_wrapper.cpp:1168-1299 (declared optix/guiding_gpu.h:35-41). */
+PT_EXPORT void guiding_upload_snapshot(const struct pgl_region* regions, uint32_t n_regions,
+                                       const struct pgl_lobe* lobes, uint32_t n_lobes);
+PT_EXPORT void guiding_set_enabled(int enabled);
+PT_EXPORT void guiding_set_train_buffer_size(uint32_t n);
+/* Returns a pointer into library-owned storage valid until the next call.  Unlike
+ * optix_wrapper.cpp:1279-1285 the count is clamped to the ring capacity. */
+PT_EXPORT void guiding_map_train_samples(const TrainSample** samples, uint32_t* count);
+PT_EXPORT void guiding_reset_train_write_idx(void);
+PT_EXPORT void guiding_set_grid_res(int x, int y, int z);
+
+/* optix/openpgl_bridge.h:7-33.  OpenPGL is not available to this build; these are a
+ * stand-in trainer with the same ABI (per-region vMF moment fit), NOT OpenPGL. */
+typedef void* pgl_dev_t;
+typedef void* pgl_field_t;
+typedef void* pgl_samples_t;
+PT_EXPORT pgl_dev_t     pgl_dev_create(int num_threads);
+PT_EXPORT void          pgl_dev_destroy(pgl_dev_t);
+PT_EXPORT pgl_field_t   pgl_field_create(pgl_dev_t dev, const float world_min[3], const float world_max[3]);
+PT_EXPORT void          pgl_field_destroy(pgl_field_t);
+PT_EXPORT pgl_samples_t pgl_samples_create(void);
+PT_EXPORT void          pgl_samples_destroy(pgl_samples_t);
+PT_EXPORT void pgl_samples_add_surface(pgl_samples_t s, const float pos[3], const float dir_in[3],
+                                       const float weight_rgb[3], int is_delta);
+PT_EXPORT void pgl_field_update(pgl_field_t, pgl_samples_t);
+PT_EXPORT void pgl_field_snapshot(pgl_field_t, const struct pgl_region** regions, uint32_t* region_count,
+                                  const struct pgl_lobe** lobes, uint32_t* lobe_count);
+
+/* ====================================================================== *
+ * Part 2 -- additions (no counterpart in the reference)                   *
+ * ====================================================================== */
+
+/* Render mode.  PT_MODE_STRICT replays the reference literally: each 4-sample launch
+ * re-derives the seed and restarts the sample index (optix_wrapper.cpp:983-1021,
+ * optix_device.cu:945-953), so N spp are N/4 repeats of the same 4 paths.
+ * PT_MODE_CONVERGE (default) feeds the global sample index into the jitter hash and
+ * continues the PCG stream, so N spp are N distinct samples of the same estimator.
+ * Also settable with the environment variable PT_MODE=strict|converge. */
+enum { PT_MODE_STRICT = 0, PT_MODE_CONVERGE = 1 };
+PT_EXPORT void pt_set_mode(int mode);
+PT_EXPORT int  pt_get_mode(void);
+
+/* Integrator pipeline.  PT_PIPELINE_STAGED runs generate / extend / shade / occlude as
+ * separate kernels over SoA queues in HBM; PT_PIPELINE_FUSED keeps a path in registers
+ * for several bounces per launch.  Same results.  Env: PT_PIPELINE=staged|fused. */
+enum { PT_PIPELINE_STAGED = 0, PT_PIPELINE_FUSED = 1 };
+PT_EXPORT void pt_set_pipeline(int pipeline);
+PT_EXPORT int  pt_get_pipeline(void);
+
+/* Select the HIP device the next renderer is created on (default 0, or env PT_DEVICE). */
+PT_EXPORT void pt_set_device(int device);
+
+/* Frame counter: the reference increments Params.frame once per render call
+ * (optix_wrapper.cpp:983); tests pin it.  The next render uses frame = value + 1. */
+PT_EXPORT void pt_set_frame(int frame);
+PT_EXPORT int  pt_get_frame(void);
+
+/* Sample-sharded, device-resident render for multi-GPU hosts.  Renders samples
+ * [sample_begin, sample_begin + sample_count) of every pixel in converge mode and ADDS
+ * the per-pixel sums into d_sum_rgb (device pointer, w*h*3 floats, caller-zeroed); the
+ * caller all-reduces the sums (RCCL) and divides by the total count.  frame is explicit
+ * so every rank uses the same one.  A chunk starting at sample_begin > 0 re-seeds the
+ * per-pixel PCG stream, so G chunks on one GPU equal G ranks with one chunk each. */
+PT_EXPORT int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth,
+                                          int frame, float* d_sum_rgb);
+/* d_rgb (w*h*3, device) -> mosaic d_raw (w*h, device); value = max(channel / divisor, 0). */
+PT_EXPORT int pt_mosaic_device(const float* d_rgb, int w, int h, int pattern, float divisor, float* d_raw);
+
+/* Demosaic (src/main.rs:190-415) on the GPU.  algo 0 = gradient method ("AMaZE" in the
+ * reference), 1 = bilinear.  Host-pointer and device-pointer forms. */
+PT_EXPORT int pt_demosaic_f32(const float* raw, int w, int h, int pattern, int algo, float* out_rgb);
+PT_EXPORT int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, int algo, float* d_out_rgb);
+
+/* src/main.rs:420-435: write w*h RGB f32 (times exposure) as a scanline OpenEXR file. */
+PT_EXPORT int pt_write_exr(const char* path, int w, int h, const float* rgb, float exposure);
+/* Minimal reader for files written by pt_write_exr (tests). Returns 0 on success. */
+PT_EXPORT int pt_read_exr(const char* path, int* w, int* h, float* rgb_or_null, size_t capacity_floats);
+
+/* Measurement.  Ray = one BVH query (radiance or shadow).  Counters accumulate over
+ * render calls until reset. */
+PT_EXPORT void pt_get_ray_counts(uint64_t* radiance_rays, uint64_t* shadow_rays);
+PT_EXPORT void pt_reset_ray_counts(void);
+/* Per-kernel GPU time measured with HIP events on the render stream.  Index: 0 generate,
+ * 1 extend, 2 shade, 3 occlude, 4 fused bounce, 5 demosaic.  Timing is sampled on every
+ * launch when enabled (pt_set_kernel_timing(1)); off by default. */
+enum { PT_K_GENERATE = 0, PT_K_EXTEND = 1, PT_K_SHADE = 2, PT_K_OCCLUDE = 3, PT_K_BOUNCE = 4, PT_K_DEMOSAIC = 5, PT_K_COUNT = 6 };
+PT_EXPORT void pt_set_kernel_timing(int every_nth_launch);
+PT_EXPORT void pt_get_kernel_stats(int kernel, double* total_ms, uint64_t* timed_launches, uint64_t* launches,
+                                   uint64_t* work_items);
+PT_EXPORT void pt_reset_kernel_stats(void);
+/* Wall time of the device work of the last render call (HIP events around the whole loop). */
+PT_EXPORT double pt_last_render_ms(void);
+
+/* Scene.  The built-in scene is the reference's Cornell box (optix_wrapper.cpp:379-489).
+ * pt_scene_synthetic replaces it by the box plus a seeded grid of triangulated spheres
+ * (about n_objects * 20 * 4^subdiv triangles) to stress BVH traversal out of HBM;
+ * pt_scene_triangles installs caller geometry (materials: 11 floats per triangle in
+ * HitData order, optix_wrapper.cpp:162-170; NULL = white diffuse).  pt_scene_cornell
+ * restores the default.  All take effect at the next render. */
+PT_EXPORT void pt_scene_cornell(void);
+PT_EXPORT void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv);
+PT_EXPORT void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
+                                  const float* materials11);
+PT_EXPORT void pt_scene_info(int* n_triangles, int* n_bvh_nodes, int* bvh_depth, size_t* bvh_bytes);
+/* Copy out the active scene (tests compare it with the oracle's). Any pointer may be NULL. */
+PT_EXPORT void pt_scene_get(float* vertices, uint32_t* indices, float* normals, float* materials11);
+
+/* Stage-level entry points (host pointers) used by the parity tests. */
+/* a3/a4: first n outputs of the RNG pieces. */
+PT_EXPORT int pt_dbg_pcg(uint64_t seed, int n, uint32_t* out_u32, float* out_f32);
+PT_EXPORT int pt_dbg_blue_noise(int n, const int* xysf /* n*4: x,y,s,frame */, float* out_uv /* n*2 */, float* out_jitter /* n*2 */);
+/* a5: camera directions for n pixels with given jitter (n*2). */
+PT_EXPORT int pt_dbg_camera_dirs(int w, int h, int n, const int* xy, const float* jitter, float* out_dirs);
+/* a7: trace n rays through the BVH kernel.  any_hit = 0: closest hit -> prim,t,b1,b2
+ * (prim = -1 on miss); any_hit = 1: prim = 1 if occluded else 0. */
+PT_EXPORT int pt_trace_rays(int n, const float* origins, const float* dirs, const float* tmin, const float* tmax,
+                            int any_hit, int* out_prim, float* out_t, float* out_b1, float* out_b2);
+/* a8: one shading step per record.  Layout mirrors PRD (optix_device.cu:227-242). */
+typedef struct pt_path_rec {
+  float radiance[3]; float throughput[3]; float origin[3]; float direction[3];
+  uint64_t seed; int depth; int done; float prev_pdf_bsdf; int prev_pdf_valid;
+  int px, py, sample, rng_dim;
+} pt_path_rec;
+PT_EXPORT int pt_dbg_shade(int n, pt_path_rec* recs, const int* prim, const float* b1, const float* b2,
+                           int frame, int max_depth, int* out_shadow_traced);
+/* a13: guiding math on the device for n queries against the uploaded snapshot. */
+PT_EXPORT int pt_dbg_guiding(int n, const float* positions, const float* u3 /* n*3 */, const float* wi /* n*3 */,
+                             int* out_region, int* out_lobe, float* out_dir /* n*3 */, float* out_pdf_dir,
+                             float* out_pdf_wi);
+
+PT_EXPORT const char* pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

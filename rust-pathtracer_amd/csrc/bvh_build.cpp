@@ -1,0 +1,323 @@
+// bvh_build.cpp -- binned-SAH binary build, greedy collapse to 8-wide nodes, octant-ordered
+// slot assignment and 8-bit box quantisation.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace pt {
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int k = 0; k < 3; ++k) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
+  }
+  void grow(const Box& b) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+  }
+  void grow(const float* p) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+  }
+  float half_area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0.f) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Node2 {
+  Box box;
+  int left = -1, right = -1;  // internal
+  int first = 0, count = 0;   // leaf when count > 0
+};
+
+constexpr int kBins = 16;
+constexpr int kMaxLeaf = 3;
+
+struct Builder {
+  const float* verts;
+  const uint32_t* idx;
+  std::vector<Box> tri_box;
+  std::vector<float> centroid;  // 3 per triangle
+  std::vector<uint32_t> order;  // triangle permutation
+  std::vector<Node2> nodes2;
+
+  int build2(int first, int count) {
+    Node2 n;
+    n.box.reset();
+    Box cb;
+    cb.reset();
+    for (int i = first; i < first + count; ++i) {
+      n.box.grow(tri_box[order[i]]);
+      cb.grow(&centroid[3 * (size_t)order[i]]);
+    }
+    const int id = (int)nodes2.size();
+    nodes2.push_back(n);
+    if (count == 1) {
+      nodes2[id].first = first;
+      nodes2[id].count = count;
+      return id;
+    }
+    // best binned SAH split over the three axes
+    float best_cost = FLT_MAX;
+    int best_axis = -1, best_bin = -1;
+    for (int axis = 0; axis < 3; ++axis) {
+      const float lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
+      if (!(ext > 0.f)) continue;
+      Box bb[kBins];
+      int bc[kBins];
+      for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+      const float scale = (float)kBins / ext;
+      for (int i = first; i < first + count; ++i) {
+        const uint32_t t = order[i];
+        int b = (int)((centroid[3 * (size_t)t + axis] - lo) * scale);
+        b = std::min(std::max(b, 0), kBins - 1);
+        bb[b].grow(tri_box[t]);
+        bc[b]++;
+      }
+      float right_area[kBins];
+      int right_cnt[kBins];
+      Box acc;
+      acc.reset();
+      int c = 0;
+      for (int b = kBins - 1; b > 0; --b) {
+        acc.grow(bb[b]);
+        c += bc[b];
+        right_area[b] = acc.half_area();
+        right_cnt[b] = c;
+      }
+      acc.reset();
+      c = 0;
+      for (int b = 0; b < kBins - 1; ++b) {
+        acc.grow(bb[b]);
+        c += bc[b];
+        if (c == 0 || right_cnt[b + 1] == 0) continue;
+        const float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+      }
+    }
+    const float parent_area = nodes2[id].box.half_area();
+    if (count <= kMaxLeaf) {
+      // leaf cost: count triangle tests; split cost: one more node level plus the children
+      const float leaf_cost = (float)count * parent_area;
+      const float split_cost = best_axis < 0 ? FLT_MAX : 1.0f * parent_area + best_cost;
+      if (leaf_cost <= split_cost) {
+        nodes2[id].first = first;
+        nodes2[id].count = count;
+        return id;
+      }
+    }
+    int mid;
+    if (best_axis < 0) {
+      mid = first + count / 2;  // all centroids coincide: split by position in the list
+    } else {
+      const float lo = cb.lo[best_axis], scale = (float)kBins / (cb.hi[best_axis] - cb.lo[best_axis]);
+      auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+        int b = (int)((centroid[3 * (size_t)t + best_axis] - lo) * scale);
+        b = std::min(std::max(b, 0), kBins - 1);
+        return b <= best_bin;
+      });
+      mid = (int)(it - order.begin());
+      if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    const int l = build2(first, mid - first);
+    const int r = build2(mid, first + count - mid);
+    nodes2[id].left = l;
+    nodes2[id].right = r;
+    return id;
+  }
+};
+
+struct Emitter {
+  const Builder& b;
+  BvhBuildResult& out;
+  uint32_t tri_cursor = 0;
+
+  void write_tri(uint32_t slot_index, uint32_t prim) {
+    const uint32_t* t = b.idx + 3 * (size_t)prim;
+    for (int k = 0; k < 3; ++k) {
+      const float* v = b.verts + 3 * (size_t)t[k];
+      q4 q{v[0], v[1], v[2], 0.f};
+      if (k == 0) q.w = u2f(prim);
+      out.tris[3 * (size_t)slot_index + k] = q;
+    }
+  }
+
+  // returns the number of internal-node levels below and including this node
+  int emit(uint32_t out_index, int n2) {
+    // gather up to 8 children by repeatedly opening the largest internal child
+    int child[8];
+    int nchild = 0;
+    const Node2& root = b.nodes2[n2];
+    if (root.count > 0) {
+      child[nchild++] = n2;
+    } else {
+      child[nchild++] = root.left;
+      child[nchild++] = root.right;
+      while (nchild < 8) {
+        int best = -1;
+        float best_area = -1.f;
+        for (int i = 0; i < nchild; ++i) {
+          const Node2& c = b.nodes2[child[i]];
+          if (c.count > 0) continue;
+          const float a = c.box.half_area();
+          if (a > best_area) { best_area = a; best = i; }
+        }
+        if (best < 0) break;
+        const Node2& c = b.nodes2[child[best]];
+        child[best] = c.left;
+        child[nchild++] = c.right;
+      }
+    }
+    // node box and grid
+    Box nb;
+    nb.reset();
+    for (int i = 0; i < nchild; ++i) nb.grow(b.nodes2[child[i]].box);
+    const float cx = 0.5f * (nb.lo[0] + nb.hi[0]), cy = 0.5f * (nb.lo[1] + nb.hi[1]), cz = 0.5f * (nb.lo[2] + nb.hi[2]);
+    // slot assignment: a child placed in slot s should lie towards the corner
+    // ((s&4)?+x:-x, (s&2)?+y:-y, (s&1)?+z:-z) of the node, so that visiting slots in the
+    // order (slot ^ octinv) descending walks the children front to back for any ray octant.
+    int slot_of[8];
+    bool slot_used[8] = {false, false, false, false, false, false, false, false};
+    bool child_done[8] = {false, false, false, false, false, false, false, false};
+    float cost[8][8];
+    for (int i = 0; i < nchild; ++i) {
+      const Box& cb = b.nodes2[child[i]].box;
+      const float ox = 0.5f * (cb.lo[0] + cb.hi[0]) - cx, oy = 0.5f * (cb.lo[1] + cb.hi[1]) - cy, oz = 0.5f * (cb.lo[2] + cb.hi[2]) - cz;
+      for (int s = 0; s < 8; ++s)
+        cost[i][s] = ((s & 4) ? ox : -ox) + ((s & 2) ? oy : -oy) + ((s & 1) ? oz : -oz);
+    }
+    for (int round = 0; round < nchild; ++round) {
+      int bi = -1, bs = -1;
+      float bc = -FLT_MAX;
+      for (int i = 0; i < nchild; ++i) {
+        if (child_done[i]) continue;
+        for (int s = 0; s < 8; ++s) {
+          if (slot_used[s]) continue;
+          if (cost[i][s] > bc) { bc = cost[i][s]; bi = i; bs = s; }
+        }
+      }
+      slot_of[bi] = bs;
+      child_done[bi] = true;
+      slot_used[bs] = true;
+    }
+    int child_in_slot[8];
+    for (int s = 0; s < 8; ++s) child_in_slot[s] = -1;
+    for (int i = 0; i < nchild; ++i) child_in_slot[slot_of[i]] = child[i];
+
+    BvhNode node;
+    memset(&node, 0, sizeof(node));
+    node.px = nb.lo[0]; node.py = nb.lo[1]; node.pz = nb.lo[2];
+    int e[3];
+    for (int k = 0; k < 3; ++k) {
+      const double ext = (double)nb.hi[k] - (double)nb.lo[k];
+      int ek = -126;
+      if (ext > 0.0) {
+        ek = (int)std::ceil(std::log2(ext / 255.0));
+        while (std::ldexp(255.0, ek) < ext) ++ek;
+        ek = std::max(ek, -126);
+      }
+      e[k] = ek;
+    }
+    node.ex = (uint8_t)(e[0] + 127); node.ey = (uint8_t)(e[1] + 127); node.ez = (uint8_t)(e[2] + 127);
+
+    int n_internal = 0;
+    for (int s = 0; s < 8; ++s)
+      if (child_in_slot[s] >= 0 && b.nodes2[child_in_slot[s]].count == 0) n_internal++;
+    const uint32_t child_base = (uint32_t)out.nodes.size();
+    out.nodes.resize(out.nodes.size() + (size_t)n_internal);
+    node.child_base = child_base;
+    node.tri_base = tri_cursor;
+    uint32_t tri_off = 0;
+    uint8_t* qlo[3] = {node.qlox, node.qloy, node.qloz};
+    uint8_t* qhi[3] = {node.qhix, node.qhiy, node.qhiz};
+    for (int s = 0; s < 8; ++s) {
+      const int c = child_in_slot[s];
+      if (c < 0) {
+        node.meta[s] = 0;
+        for (int k = 0; k < 3; ++k) { qlo[k][s] = 255; qhi[k][s] = 0; }
+        continue;
+      }
+      const Node2& cn = b.nodes2[c];
+      for (int k = 0; k < 3; ++k) {
+        const double sc = std::ldexp(1.0, e[k]);
+        double lo = std::floor(((double)cn.box.lo[k] - (double)nb.lo[k]) / sc);
+        double hi = std::ceil(((double)cn.box.hi[k] - (double)nb.lo[k]) / sc);
+        qlo[k][s] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
+        qhi[k][s] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
+      }
+      if (cn.count == 0) {
+        node.imask |= (uint8_t)(1u << s);
+        node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
+      } else {
+        const uint32_t unary = cn.count == 1 ? 1u : (cn.count == 2 ? 3u : 7u);
+        node.meta[s] = (uint8_t)((unary << 5) | tri_off);
+        for (int i = 0; i < cn.count; ++i) write_tri(tri_cursor + tri_off + (uint32_t)i, b.order[cn.first + i]);
+        tri_off += (uint32_t)cn.count;
+      }
+    }
+    tri_cursor += tri_off;
+    out.nodes[out_index] = node;
+
+    int depth_below = 0;
+    uint32_t rank = 0;
+    for (int s = 0; s < 8; ++s) {
+      const int c = child_in_slot[s];
+      if (c < 0 || b.nodes2[c].count > 0) continue;
+      depth_below = std::max(depth_below, emit(child_base + rank, c));
+      rank++;
+    }
+    return 1 + depth_below;
+  }
+};
+
+}  // namespace
+
+BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int num_tris) {
+  BvhBuildResult out;
+  out.num_tris = num_tris;
+  if (num_tris <= 0) {
+    // a single empty node: every ray misses
+    BvhNode n;
+    memset(&n, 0, sizeof(n));
+    n.ex = n.ey = n.ez = 1;
+    for (int s = 0; s < 8; ++s) { n.qlox[s] = n.qloy[s] = n.qloz[s] = 255; }
+    out.nodes.push_back(n);
+    out.depth = 1;
+    return out;
+  }
+  Builder b;
+  b.verts = vertices;
+  b.idx = indices;
+  b.tri_box.resize((size_t)num_tris);
+  b.centroid.resize(3 * (size_t)num_tris);
+  b.order.resize((size_t)num_tris);
+  std::iota(b.order.begin(), b.order.end(), 0u);
+  for (int t = 0; t < num_tris; ++t) {
+    Box bx;
+    bx.reset();
+    for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)t + k]);
+    for (int k = 0; k < 3; ++k) {
+      b.centroid[3 * (size_t)t + k] = 0.5f * (bx.lo[k] + bx.hi[k]);
+      // pad so that rays grazing a flat or grid-aligned box are not lost to rounding
+      const float pad = 1e-6f * std::max(std::max(std::fabs(bx.lo[k]), std::fabs(bx.hi[k])), 1e-3f);
+      bx.lo[k] -= pad;
+      bx.hi[k] += pad;
+    }
+    b.tri_box[(size_t)t] = bx;
+  }
+  b.nodes2.reserve(2 * (size_t)num_tris);
+  const int root2 = b.build2(0, num_tris);
+  out.tris.resize(3 * (size_t)num_tris);
+  out.nodes.reserve((size_t)num_tris / 2 + 16);
+  out.nodes.resize(1);
+  Emitter em{b, out};
+  out.depth = em.emit(0, root2);
+  return out;
+}
+
+}  // namespace pt

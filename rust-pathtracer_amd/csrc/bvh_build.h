@@ -1,0 +1,23 @@
+// bvh_build.h -- host-side SAH builder for the compressed 8-wide BVH.
+//
+// Takes the place of optixAccelBuild on the driver (optix_wrapper.cpp:492-544): one
+// triangle soup in, one traversable structure out.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "pt_types.h"
+
+namespace pt {
+
+struct BvhBuildResult {
+  std::vector<BvhNode> nodes;  // node 0 is the root
+  std::vector<q4> tris;        // 3 x q4 per triangle in leaf order; tris[3i].w = primitive index bits
+  int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
+  int num_tris = 0;
+};
+
+// vertices: 3 floats each; indices: 3 per triangle.
+BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int num_tris);
+
+}  // namespace pt

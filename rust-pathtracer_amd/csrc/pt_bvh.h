@@ -1,0 +1,215 @@
+// pt_bvh.h -- software ray casting for gfx950 (a7): traversal of the compressed 8-wide BVH
+// with a short per-lane stack, and a watertight two-sided ray/triangle test.
+//
+// Replaces what the reference gets from optixTrace + the driver-built GAS
+// (optix_device.cu:508-520, 976-986; optix_wrapper.cpp:492-544): closest hit returning the
+// primitive index and barycentrics (b1,b2) of v1,v2, or first-hit termination for shadow
+// rays.  The ray interval is open: (tmin, tmax).
+#pragma once
+#include "pt_types.h"
+
+namespace pt {
+
+struct Hit {
+  int prim;  // -1: miss
+  float t, b1, b2;
+};
+
+// Traversal stack entry: {base index, hit bits}.  Node group: bits 24..31 are the still
+// unvisited child slots in front-to-back priority order, bits 0..7 the node's imask.
+// One entry per BVH level at most.
+struct StackEntry {
+  uint32_t base, bits;
+};
+
+// Per-ray constants of the watertight test (Woop, Benthin, Wald, JCGT 2013).  The shear
+// "translate, permute so the dominant axis is z, shear x/y" is folded into three row
+// vectors so no per-vertex component selection is needed:
+//   Ax = dot(A, rx), Ay = dot(A, ry), Az = dot(A, rz)
+// Every vertex goes through the same instruction sequence for a given ray, so vertices
+// shared by two triangles get identical (Ax, Ay) and the edge functions below agree on
+// shared edges.
+struct RayShear {
+  f3 rx, ry, rz;
+};
+
+PT_HD RayShear make_shear(f3 d) {
+  float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+  int kx = kz == 2 ? 0 : kz + 1;
+  int ky = kx == 2 ? 0 : kx + 1;
+  float dz = comp(d, kz);
+  if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+  float inv = rcp(dz);
+  float sx = comp(d, kx) * inv, sy = comp(d, ky) * inv;
+  RayShear r;
+  r.rx = mk3(kx == 0 ? 1.0f : (kz == 0 ? -sx : 0.0f), kx == 1 ? 1.0f : (kz == 1 ? -sx : 0.0f),
+             kx == 2 ? 1.0f : (kz == 2 ? -sx : 0.0f));
+  r.ry = mk3(ky == 0 ? 1.0f : (kz == 0 ? -sy : 0.0f), ky == 1 ? 1.0f : (kz == 1 ? -sy : 0.0f),
+             ky == 2 ? 1.0f : (kz == 2 ? -sy : 0.0f));
+  r.rz = mk3(kz == 0 ? inv : 0.0f, kz == 1 ? inv : 0.0f, kz == 2 ? inv : 0.0f);
+  return r;
+}
+
+// Edge functions must not be contracted into FMAs: U for edge (B,C) in one triangle has
+// to be the exact negation of the same edge seen from the neighbouring triangle.
+PT_HD void edge_functions(float Ax, float Ay, float Bx, float By, float Cx, float Cy, float& U, float& V, float& W) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  float cxby = Cx * By, cybx = Cy * Bx;
+  float axcy = Ax * Cy, aycx = Ay * Cx;
+  float bxay = Bx * Ay, byax = By * Ax;
+  U = cxby - cybx;
+  V = axcy - aycx;
+  W = bxay - byax;
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+}
+
+// Returns true and updates hit when the triangle is hit inside (tmin, hit.t).
+PT_HD bool intersect_triangle(const RayShear& rs, f3 o, f3 v0, f3 v1, f3 v2, float tmin, int prim, Hit& hit) {
+  const f3 A = v0 - o, B = v1 - o, C = v2 - o;
+  const float Ax = dot(A, rs.rx), Ay = dot(A, rs.ry);
+  const float Bx = dot(B, rs.rx), By = dot(B, rs.ry);
+  const float Cx = dot(C, rs.rx), Cy = dot(C, rs.ry);
+  float U, V, W;
+  edge_functions(Ax, Ay, Bx, By, Cx, Cy, U, V, W);
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  float det = U + V + W;
+  if (det == 0.0f) return false;
+  const float Az = dot(A, rs.rz), Bz = dot(B, rs.rz), Cz = dot(C, rs.rz);
+  float T = U * Az + V * Bz + W * Cz;
+  if (det < 0.0f) { T = -T; det = -det; }
+  if (!(T > tmin * det) || !(T < hit.t * det)) return false;
+  const float r = rcp(det);
+  hit.t = T * r;
+  hit.b1 = fabsf(V) * r;
+  hit.b2 = fabsf(W) * r;
+  hit.prim = prim;
+  return true;
+}
+
+PT_HD float safe_inv(float d) {
+  float a = fabsf(d) < 1e-20f ? (d < 0.0f ? -1e-20f : 1e-20f) : d;
+  return rcp(a);
+}
+
+// Ray constants for the child-box tests of one node.
+struct RayBox {
+  f3 o, idir;
+  uint32_t octinv;  // bit2: d.x >= 0, bit1: d.y >= 0, bit0: d.z >= 0
+};
+
+// A node as the five 16-byte words it is loaded with.
+struct NodeWords {
+  u4 q[5];
+};
+PT_HD NodeWords load_node(const BvhNode* nodes, uint32_t idx) {
+  const u4* p = reinterpret_cast<const u4*>(nodes) + 5u * idx;
+  NodeWords n;
+  n.q[0] = p[0]; n.q[1] = p[1]; n.q[2] = p[2]; n.q[3] = p[3]; n.q[4] = p[4];
+  return n;
+}
+PT_HD float byte_f(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xffu); }
+
+// Slab test of the node's 8 quantised child boxes; returns the hit bits
+// (children: 24 + (slot ^ octinv); triangles: their offsets in the node's triangle range).
+PT_HD uint32_t intersect_children(const NodeWords& n, const RayBox& rb, float tmin, float tmax) {
+  const uint32_t ew = n.q[0].w;  // ex | ey<<8 | ez<<16 | imask<<24
+  const float sx = u2f((ew & 0xffu) << 23) * rb.idir.x;
+  const float sy = u2f(((ew >> 8) & 0xffu) << 23) * rb.idir.y;
+  const float sz = u2f(((ew >> 16) & 0xffu) << 23) * rb.idir.z;
+  const float bx = (u2f(n.q[0].x) - rb.o.x) * rb.idir.x;
+  const float by = (u2f(n.q[0].y) - rb.o.y) * rb.idir.y;
+  const float bz = (u2f(n.q[0].z) - rb.o.z) * rb.idir.z;
+  const bool px = (rb.octinv & 4u) != 0u, py = (rb.octinv & 2u) != 0u, pz = (rb.octinv & 1u) != 0u;
+  // words: q[2] = qlox[0..7] qloy[0..7]; q[3] = qloz[0..7] qhix[0..7]; q[4] = qhiy[0..7] qhiz[0..7]
+  const uint32_t lox[2] = {n.q[2].x, n.q[2].y}, loy[2] = {n.q[2].z, n.q[2].w}, loz[2] = {n.q[3].x, n.q[3].y};
+  const uint32_t hix[2] = {n.q[3].z, n.q[3].w}, hiy[2] = {n.q[4].x, n.q[4].y}, hiz[2] = {n.q[4].z, n.q[4].w};
+  const uint32_t meta[2] = {n.q[1].z, n.q[1].w};
+  const uint32_t octinv4 = rb.octinv * 0x01010101u;
+  uint32_t mask = 0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const uint32_t m4 = meta[half];
+    const uint32_t is_inner4 = (m4 & (m4 << 1)) & 0x10101010u;
+    const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+    const uint32_t bit_index4 = (m4 ^ (octinv4 & inner_mask4)) & 0x1f1f1f1fu;
+    const uint32_t child_bits4 = (m4 >> 5) & 0x07070707u;
+    const uint32_t nxw = px ? lox[half] : hix[half], fxw = px ? hix[half] : lox[half];
+    const uint32_t nyw = py ? loy[half] : hiy[half], fyw = py ? hiy[half] : loy[half];
+    const uint32_t nzw = pz ? loz[half] : hiz[half], fzw = pz ? hiz[half] : loz[half];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float tnx = byte_f(nxw, j) * sx + bx, tfx = byte_f(fxw, j) * sx + bx;
+      const float tny = byte_f(nyw, j) * sy + by, tfy = byte_f(fyw, j) * sy + by;
+      const float tnz = byte_f(nzw, j) * sz + bz, tfz = byte_f(fzw, j) * sz + bz;
+      const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
+      if (tn <= tf) mask |= ((child_bits4 >> (8 * j)) & 0xffu) << ((bit_index4 >> (8 * j)) & 0xffu);
+    }
+  }
+  return mask;
+}
+
+// Stack policies: push(level, entry) / pop(level).
+struct LocalStack {
+  StackEntry e[64];
+  PT_HD void push(int sp, StackEntry v) { e[sp] = v; }
+  PT_HD StackEntry pop(int sp) const { return e[sp]; }
+};
+
+PT_HD f3 ldv(const q4& q) { return mk3(q.x, q.y, q.z); }
+
+// Closest hit (any_hit = false) or first hit (any_hit = true; hit.prim >= 0 means occluded).
+template <class Stack>
+PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, bool any_hit, Stack& stack, int stack_limit) {
+  Hit hit{-1, tmax, 0.f, 0.f};
+  RayBox rb;
+  rb.o = o;
+  rb.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  rb.octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+  const RayShear rs = make_shear(d);
+
+  StackEntry cur{0u, 0x80000000u};
+  int sp = 0;
+  for (;;) {
+    StackEntry tg;
+    if (cur.bits & 0xff000000u) {
+      const uint32_t hits_imask = cur.bits;
+      const int bit = 31 - __builtin_clz(hits_imask);
+      cur.bits &= ~(1u << bit);
+      if ((cur.bits & 0xff000000u) && sp < stack_limit) stack.push(sp++, cur);
+      const uint32_t slot = (uint32_t)(bit - 24) ^ rb.octinv;
+      const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+      const NodeWords n = load_node(sc.nodes, cur.base + rel);
+      const uint32_t hm = intersect_children(n, rb, tmin, hit.t);
+      cur.base = n.q[1].x;
+      cur.bits = (hm & 0xff000000u) | (n.q[0].w >> 24);
+      tg.base = n.q[1].y;
+      tg.bits = hm & 0x00ffffffu;
+    } else {
+      tg = cur;
+      cur.base = 0u;
+      cur.bits = 0u;
+    }
+    while (tg.bits) {
+      const int ti = __builtin_ctz(tg.bits);
+      tg.bits &= tg.bits - 1u;
+      const q4* tp = sc.tris + 3u * (tg.base + (uint32_t)ti);
+      const q4 a = tp[0], b = tp[1], c = tp[2];
+      if (intersect_triangle(rs, o, ldv(a), ldv(b), ldv(c), tmin, (int)f2u(a.w), hit) && any_hit) return hit;
+    }
+    if ((cur.bits & 0xff000000u) == 0u) {
+      if (sp == 0) break;
+      cur = stack.pop(--sp);
+    }
+  }
+  return hit;
+}
+
+}  // namespace pt

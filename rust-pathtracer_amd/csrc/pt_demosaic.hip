@@ -1,0 +1,198 @@
+// pt_demosaic.hip -- Bayer demosaic on the GPU (a16), bit-compatible with the reference's
+// sequential CPU loops (src/main.rs:190-342 gradient method, 344-401 bilinear).
+//
+// The reference runs six in-place passes over three colour planes.  In every pass a site
+// writes only itself and reads only sites that the pass does not write (or itself, through
+// border clamping, before its own write), so each pass is a data-parallel gather.  Here:
+//   k_green   raw            -> g     (passes 0+1: plane split folded into the reads)
+//   k_rb_at_g raw, g         -> r, b  (pass 2; red/blue sites carry their raw value / 0)
+//   k_rb_diag r, g, b        -> r, b  (pass 3, in place)
+//   k_combine r, g, b        -> rgb   (passes 4-6: chroma planes formed on the fly)
+// Arithmetic is plain fp32 in the reference's operation order; this file is compiled with
+// FMA contraction off and correctly rounded division so results match bit for bit.
+#include "pt_kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace pt {
+
+enum { CFA_R = 0, CFA_G = 1, CFA_B = 2 };
+
+// src/main.rs:157-173
+__device__ __forceinline__ int cfa_at(int x, int y, int pattern) {
+  const int p = pattern < 0 ? 0 : (pattern > 3 ? 3 : pattern);
+  const int my = y & 1, mx = x & 1;
+  // rows of the four 2x2 tables, 2 bits per entry: R=0 G=1 B=2
+  // p0 RGGB: [R G; G B]  p1 BGGR: [B G; G R]  p2 GRBG: [G R; B G]  p3 GBRG: [G B; R G]
+  const unsigned tables[4] = {0x0u | (1u << 2) | (1u << 4) | (2u << 6), 2u | (1u << 2) | (1u << 4) | (0u << 6),
+                              1u | (0u << 2) | (2u << 4) | (1u << 6), 1u | (2u << 2) | (0u << 4) | (1u << 6)};
+  return (int)((tables[p] >> (2 * (my * 2 + mx))) & 3u);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// src/main.rs:175-179
+__device__ __forceinline__ float getf(const float* img, int w, int h, int x, int y) {
+  return img[(size_t)clampi(y, 0, h - 1) * (size_t)w + (size_t)clampi(x, 0, w - 1)];
+}
+// plane value of colour c at a (clamped) site straight from the mosaic: raw where the CFA
+// has colour c, 0 elsewhere (src/main.rs:192-204)
+__device__ __forceinline__ float plane_raw(const float* raw, int w, int h, int x, int y, int pattern, int c) {
+  const int xx = clampi(x, 0, w - 1), yy = clampi(y, 0, h - 1);
+  return cfa_at(xx, yy, pattern) == c ? raw[(size_t)yy * w + xx] : 0.0f;
+}
+
+// src/main.rs:205-237
+__global__ void k_green(const float* raw, float* g, int w, int h, int pattern) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const int c = cfa_at(x, y, pattern);
+  const size_t i = (size_t)y * w + x;
+  if (c == CFA_G) { g[i] = raw[i]; return; }
+  const float c0 = plane_raw(raw, w, h, x, y, pattern, c);
+  const float c_l2 = plane_raw(raw, w, h, x - 2, y, pattern, c), c_l1 = plane_raw(raw, w, h, x - 1, y, pattern, c);
+  const float c_r1 = plane_raw(raw, w, h, x + 1, y, pattern, c), c_r2 = plane_raw(raw, w, h, x + 2, y, pattern, c);
+  const float c_u2 = plane_raw(raw, w, h, x, y - 2, pattern, c), c_u1 = plane_raw(raw, w, h, x, y - 1, pattern, c);
+  const float c_d1 = plane_raw(raw, w, h, x, y + 1, pattern, c), c_d2 = plane_raw(raw, w, h, x, y + 2, pattern, c);
+  const float g_l1 = plane_raw(raw, w, h, x - 1, y, pattern, CFA_G), g_r1 = plane_raw(raw, w, h, x + 1, y, pattern, CFA_G);
+  const float g_u1 = plane_raw(raw, w, h, x, y - 1, pattern, CFA_G), g_d1 = plane_raw(raw, w, h, x, y + 1, pattern, CFA_G);
+  const float grad_h = fabsf(g_l1 - g_r1) + fabsf(2.0f * c0 - c_l2 - c_r2) * 0.5f + fabsf(c_l1 - c_r1);
+  const float grad_v = fabsf(g_u1 - g_d1) + fabsf(2.0f * c0 - c_u2 - c_d2) * 0.5f + fabsf(c_u1 - c_d1);
+  const float gh = 0.5f * (g_l1 + g_r1) + 0.25f * (2.0f * c0 - c_l2 - c_r2);
+  const float gv = 0.5f * (g_u1 + g_d1) + 0.25f * (2.0f * c0 - c_u2 - c_d2);
+  const float wh = 1.0f / (1e-6f + grad_h * grad_h);
+  const float wv = 1.0f / (1e-6f + grad_v * grad_v);
+  g[i] = (wh * gh + wv * gv) / (wh + wv);
+}
+
+// src/main.rs:238-276
+__global__ void k_rb_at_g(const float* raw, const float* g, float* r, float* b, int w, int h, int pattern) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const size_t i = (size_t)y * w + x;
+  const int c = cfa_at(x, y, pattern);
+  if (c == CFA_R) { r[i] = raw[i]; b[i] = 0.0f; return; }
+  if (c == CFA_B) { b[i] = raw[i]; r[i] = 0.0f; return; }
+  const float g0 = g[i];
+  const bool has_red_h = cfa_at(x - 1, y, pattern) == CFA_R || cfa_at(x + 1, y, pattern) == CFA_R;
+  const bool has_red_v = cfa_at(x, y - 1, pattern) == CFA_R || cfa_at(x, y + 1, pattern) == CFA_R;
+  const bool has_blue_h = cfa_at(x - 1, y, pattern) == CFA_B || cfa_at(x + 1, y, pattern) == CFA_B;
+  const bool has_blue_v = cfa_at(x, y - 1, pattern) == CFA_B || cfa_at(x, y + 1, pattern) == CFA_B;
+  float r_est, b_est;
+  if (has_red_h)
+    r_est = 0.5f * (plane_raw(raw, w, h, x - 1, y, pattern, CFA_R) + plane_raw(raw, w, h, x + 1, y, pattern, CFA_R)) -
+            0.5f * (getf(g, w, h, x - 1, y) + getf(g, w, h, x + 1, y)) + g0;
+  else if (has_red_v)
+    r_est = 0.5f * (plane_raw(raw, w, h, x, y - 1, pattern, CFA_R) + plane_raw(raw, w, h, x, y + 1, pattern, CFA_R)) -
+            0.5f * (getf(g, w, h, x, y - 1) + getf(g, w, h, x, y + 1)) + g0;
+  else
+    r_est = g0;
+  if (has_blue_h)
+    b_est = 0.5f * (plane_raw(raw, w, h, x - 1, y, pattern, CFA_B) + plane_raw(raw, w, h, x + 1, y, pattern, CFA_B)) -
+            0.5f * (getf(g, w, h, x - 1, y) + getf(g, w, h, x + 1, y)) + g0;
+  else if (has_blue_v)
+    b_est = 0.5f * (plane_raw(raw, w, h, x, y - 1, pattern, CFA_B) + plane_raw(raw, w, h, x, y + 1, pattern, CFA_B)) -
+            0.5f * (getf(g, w, h, x, y - 1) + getf(g, w, h, x, y + 1)) + g0;
+  else
+    b_est = g0;
+  r[i] = r_est;
+  b[i] = b_est;
+}
+
+// src/main.rs:277-303
+__global__ void k_rb_diag(const float* g, float* r, float* b, int w, int h, int pattern) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const int c = cfa_at(x, y, pattern);
+  if (c == CFA_G) return;
+  float* dst = (c == CFA_R) ? b : r;  // the colour missing at this site
+  const float g0 = getf(g, w, h, x, y);
+  const float est = 0.25f * ((getf(dst, w, h, x - 1, y - 1) - getf(g, w, h, x - 1, y - 1)) +
+                             (getf(dst, w, h, x + 1, y - 1) - getf(g, w, h, x + 1, y - 1)) +
+                             (getf(dst, w, h, x - 1, y + 1) - getf(g, w, h, x - 1, y + 1)) +
+                             (getf(dst, w, h, x + 1, y + 1) - getf(g, w, h, x + 1, y + 1))) + g0;
+  dst[(size_t)y * w + x] = est;
+}
+
+__device__ __forceinline__ float diff_at(const float* a, const float* g, int w, int h, int x, int y) {
+  const int xx = clampi(x, 0, w - 1), yy = clampi(y, 0, h - 1);
+  const size_t i = (size_t)yy * w + xx;
+  return a[i] - g[i];  // src/main.rs:306-309
+}
+// src/main.rs:304-341
+__global__ void k_combine(const float* r, const float* g, const float* b, float* out, int w, int h) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const float gh = fabsf(getf(g, w, h, x - 1, y) - getf(g, w, h, x + 1, y));
+  const float gv = fabsf(getf(g, w, h, x, y - 1) - getf(g, w, h, x, y + 1));
+  const float w_h = 1.0f / (1e-6f + gh);
+  const float w_v = 1.0f / (1e-6f + gv);
+  const float rgh = 0.5f * (diff_at(r, g, w, h, x - 1, y) + diff_at(r, g, w, h, x + 1, y));
+  const float rgv = 0.5f * (diff_at(r, g, w, h, x, y - 1) + diff_at(r, g, w, h, x, y + 1));
+  const float bgh = 0.5f * (diff_at(b, g, w, h, x - 1, y) + diff_at(b, g, w, h, x + 1, y));
+  const float bgv = 0.5f * (diff_at(b, g, w, h, x, y - 1) + diff_at(b, g, w, h, x, y + 1));
+  const float rg2 = (w_h * rgh + w_v * rgv) / (w_h + w_v);
+  const float bg2 = (w_h * bgh + w_v * bgv) / (w_h + w_v);
+  const size_t i = (size_t)y * w + x;
+  const float g0 = g[i];
+  out[3 * i + 0] = fmaxf(g0 + rg2, 0.0f);
+  out[3 * i + 1] = fmaxf(g0, 0.0f);
+  out[3 * i + 2] = fmaxf(g0 + bg2, 0.0f);
+}
+
+// src/main.rs:344-401
+__global__ void k_bilinear(const float* raw, float* out, int w, int h, int pattern) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const size_t i = (size_t)y * w + x;
+  const float v = raw[i];
+  const int c = cfa_at(x, y, pattern);
+  if (c == CFA_G) {
+    const float hor = (getf(raw, w, h, x - 1, y) + getf(raw, w, h, x + 1, y)) * 0.5f;
+    const float ver = (getf(raw, w, h, x, y - 1) + getf(raw, w, h, x, y + 1)) * 0.5f;
+    const bool red_h = cfa_at(x - 1, y, pattern) == CFA_R || cfa_at(x + 1, y, pattern) == CFA_R;
+    out[3 * i + 0] = red_h ? hor : ver;
+    out[3 * i + 1] = v;
+    out[3 * i + 2] = red_h ? ver : hor;
+  } else {
+    const float cross4 = (getf(raw, w, h, x - 1, y) + getf(raw, w, h, x + 1, y) + getf(raw, w, h, x, y - 1) +
+                          getf(raw, w, h, x, y + 1)) * 0.25f;
+    const float diag4 = (getf(raw, w, h, x - 1, y - 1) + getf(raw, w, h, x + 1, y - 1) + getf(raw, w, h, x - 1, y + 1) +
+                         getf(raw, w, h, x + 1, y + 1)) * 0.25f;
+    out[3 * i + 0] = c == CFA_R ? v : diag4;
+    out[3 * i + 1] = cross4;
+    out[3 * i + 2] = c == CFA_R ? diag4 : v;
+  }
+}
+
+#define PT_KCHECK2()                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "HIP launch error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      abort();                                                                           \
+    }                                                                                    \
+  } while (0)
+
+void launch_demosaic(const float* d_raw, float* d_out, float* d_tmp, int w, int h, int pattern, int algo, hipStream_t s) {
+  const dim3 block(64, 4);
+  const dim3 grid((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4));
+  if (algo == 1) {
+    k_bilinear<<<grid, block, 0, s>>>(d_raw, d_out, w, h, pattern);
+    PT_KCHECK2();
+    return;
+  }
+  const size_t n = (size_t)w * (size_t)h;
+  float* g = d_tmp;
+  float* r = d_tmp + n;
+  float* b = d_tmp + 2 * n;
+  k_green<<<grid, block, 0, s>>>(d_raw, g, w, h, pattern);
+  PT_KCHECK2();
+  k_rb_at_g<<<grid, block, 0, s>>>(d_raw, g, r, b, w, h, pattern);
+  PT_KCHECK2();
+  k_rb_diag<<<grid, block, 0, s>>>(g, r, b, w, h, pattern);
+  PT_KCHECK2();
+  k_combine<<<grid, block, 0, s>>>(r, g, b, d_out, w, h);
+  PT_KCHECK2();
+}
+
+}  // namespace pt

@@ -1,0 +1,83 @@
+// pt_kernels.h -- launch interface between the host runtime and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pt_types.h"
+
+namespace pt {
+
+// Device counters (uint32 words) shared by the wavefront kernels.
+enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_SHADOW = 2, CNT_WORDS = 8 };
+
+// Everything a wavefront kernel needs, passed by value (lives in the kernarg segment).
+struct RenderParams {
+  SceneView scene;
+  GuideView guide;
+  CameraView cam;
+  int width, height;
+  int frame, max_depth;
+  int sample_begin, sample_count;  // this chunk renders global samples [begin, begin+count) per pixel
+  int strict;                      // 1: replay the reference's 4-sample launches literally
+  int guiding;
+  int stack_depth;                 // traversal stack entries per lane
+  // per-pixel path state, SoA of 16-byte words
+  q4* st_o;   // origin.xyz, throughput.x
+  q4* st_d;   // direction.xyz, throughput.y
+  q4* st_s;   // sample sum.xyz, throughput.z
+  u4* st_m;   // seed lo, seed hi, prev_pdf bits, flags
+  q4* acc;    // per-pixel sum of finished samples (xyz)
+  int* started;  // samples started per pixel
+  // queues
+  uint32_t* queue[2];
+  uint32_t* counters;      // CNT_WORDS words
+  unsigned long long* ray_counters;  // [0] radiance rays, [1] shadow rays
+  q4* hits;                // per queue slot: prim bits, t, b1, b2
+  q4* sh_o;                // shadow queue: origin.xyz, tmax
+  q4* sh_d;                //               dir.xyz, pixel bits
+  q4* sh_c;                //               contrib.xyz
+  // guiding training ring (optix_device.cu:10-12)
+  TrainRec* train;
+  uint32_t* train_write_idx;
+  uint32_t train_capacity;
+};
+
+struct LaunchCfg {
+  int blocks, threads;
+  hipStream_t stream;
+};
+
+// One wavefront iteration, staged: qin -> generate -> qout; extend/shade over qout; occlude.
+void launch_generate(const RenderParams& p, int qin, const LaunchCfg& c);
+void launch_extend(const RenderParams& p, int q, const LaunchCfg& c);
+void launch_shade(const RenderParams& p, int q, const LaunchCfg& c);
+void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c);
+// Fused: up to `bounces` bounces per path in registers, regenerating finished samples in place.
+void launch_bounce(const RenderParams& p, int qin, int bounces, const LaunchCfg& c);
+
+void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);
+// out[3p+k] (+)= acc[p].k / divisor(p); mode 0: write mean (divide by started[p]); 1: add raw sums
+void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int mode, hipStream_t s);
+// mosaic: raw[p] = max(rgb[3p + ch(p)] / divisor, 0)
+void launch_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float divisor, hipStream_t s);
+
+// demosaic passes (pt_demosaic.hip)
+void launch_demosaic(const float* d_raw, float* d_out, float* d_tmp /* 7*w*h floats */, int w, int h, int pattern,
+                     int algo, hipStream_t s);
+
+// stage-level debug kernels
+void launch_dbg_pcg(unsigned long long seed, int n, uint32_t* out_u, float* out_f, hipStream_t s);
+void launch_dbg_blue_noise(int n, const int* xysf, float* uv, float* jitter, hipStream_t s);
+void launch_dbg_camera(CameraView cam, int w, int h, int n, const int* xy, const float* jitter, float* dirs, hipStream_t s);
+void launch_trace_rays(SceneView sc, int stack_depth, int n, const float* o, const float* d, const float* tmin,
+                       const float* tmax, int any_hit, int* prim, float* t, float* b1, float* b2, hipStream_t s);
+struct DbgPathRec {  // == pt_path_rec in include/pt_api.h
+  float radiance[3]; float throughput[3]; float origin[3]; float direction[3];
+  unsigned long long seed; int depth; int done; float prev_pdf_bsdf; int prev_pdf_valid;
+  int px, py, sample, rng_dim;
+};
+void launch_dbg_shade(SceneView sc, GuideView gv, int guiding, int stack_depth, int n, DbgPathRec* recs, const int* prim,
+                      const float* b1, const float* b2, int frame, int max_depth, int* shadow_traced, hipStream_t s);
+void launch_dbg_guiding(GuideView gv, int n, const float* pos, const float* u3, const float* wi, int* region, int* lobe,
+                        float* dir, float* pdf_dir, float* pdf_wi, hipStream_t s);
+
+}  // namespace pt

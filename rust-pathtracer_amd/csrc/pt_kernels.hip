@@ -1,0 +1,490 @@
+// pt_kernels.hip -- wavefront path-tracing kernels for gfx950 (MI355X).
+//
+// Work unit: one pixel owns one path slot.  A slot runs its pixel's samples one after the
+// other (the reference's raygen does the same inside one thread, optix_device.cu:953-1053),
+// so the PCG stream of a pixel is consumed in the reference's order.  Queues hold the ids
+// of pixels that still have samples to take; they are compacted with wave64 ballot +
+// popcount and one atomic per wave.
+//
+// Staged pipeline (one iteration = one bounce of every live path):
+//   generate : fold finished samples into the pixel sums, start the next sample, compact
+//   extend   : closest-hit BVH traversal of the radiance rays            -> hit records
+//   shade    : BSDF / NEE / guided sampling / Russian roulette            -> shadow queue
+//   occlude  : first-hit traversal of the shadow rays, add unoccluded NEE -> path sums
+// Fused pipeline: the same device functions chained per lane with the path in registers
+// for several bounces per launch (no hit or shadow records in HBM).
+#include "pt_kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "pt_bvh.h"
+#include "pt_shade.h"
+
+namespace pt {
+
+#define PT_KCHECK()                                                                      \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "HIP launch error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      abort();                                                                           \
+    }                                                                                    \
+  } while (0)
+
+extern __shared__ StackEntry g_lds_stack[];
+
+// Per-lane traversal stack in LDS, entry (level, lane) at [level * blockDim + lane]:
+// consecutive lanes touch consecutive 8-byte words, so pushes and pops are conflict-free.
+struct LdsStack {
+  StackEntry* base;
+  int stride;
+  __device__ __forceinline__ void push(int sp, StackEntry v) { base[sp * stride] = v; }
+  __device__ __forceinline__ StackEntry pop(int sp) const { return base[sp * stride]; }
+};
+__device__ __forceinline__ LdsStack lds_stack() { return LdsStack{g_lds_stack + threadIdx.x, (int)blockDim.x}; }
+
+__device__ __forceinline__ PathState load_state(const RenderParams& p, uint32_t px) {
+  const q4 a = p.st_o[px], b = p.st_d[px], c = p.st_s[px];
+  const u4 m = p.st_m[px];
+  PathState s;
+  s.o = mk3(a.x, a.y, a.z);
+  s.d = mk3(b.x, b.y, b.z);
+  s.sum = mk3(c.x, c.y, c.z);
+  s.T = mk3(a.w, b.w, c.w);
+  s.seed = ((uint64_t)m.y << 32) | (uint64_t)m.x;
+  s.prev_pdf = u2f(m.z);
+  s.flags = m.w;
+  return s;
+}
+__device__ __forceinline__ void store_state(const RenderParams& p, uint32_t px, const PathState& s) {
+  p.st_o[px] = q4{s.o.x, s.o.y, s.o.z, s.T.x};
+  p.st_d[px] = q4{s.d.x, s.d.y, s.d.z, s.T.y};
+  p.st_s[px] = q4{s.sum.x, s.sum.y, s.sum.z, s.T.z};
+  p.st_m[px] = u4{(uint32_t)s.seed, (uint32_t)(s.seed >> 32), f2u(s.prev_pdf), s.flags};
+}
+
+// Sample index fed to the jitter hash, and the PCG state the sample starts from.
+// strict: optix_device.cu:945-948,953 (seed re-derived and s restarted every 4 samples);
+// converge: global index, stream continues (re-seeded at a chunk start).
+__device__ __forceinline__ int hash_sample_index(const RenderParams& p, int local) {
+  return p.strict ? (local & 3) : p.sample_begin + local;
+}
+__device__ __forceinline__ uint64_t start_seed(const RenderParams& p, uint32_t pixel, int local, uint64_t carried) {
+  if (p.strict) return (local & 3) == 0 ? pixel_seed(p.frame, pixel) : carried;
+  return local == 0 ? chunk_seed(p.frame, pixel, p.sample_begin) : carried;
+}
+
+// Append `keep` lanes' values to a queue: ballot, one atomic per wave, prefix popcount.
+__device__ __forceinline__ uint32_t wave_append_slot(bool keep, uint32_t* counter) {
+  const unsigned long long mask = __ballot(keep);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == 0 && mask) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, 0);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ ShadeParams shade_params(const RenderParams& p) {
+  return ShadeParams{p.frame, p.max_depth, p.guiding};
+}
+
+__device__ __forceinline__ void append_train(const RenderParams& p, bool want, const TrainRec& rec) {
+  if (!p.train) return;
+  const unsigned long long mask = __ballot(want);
+  if (!mask) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(p.train_write_idx, (uint32_t)__popcll(mask));
+  base = __shfl(base, __builtin_ctzll(mask));
+  if (want) {
+    uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (p.train_capacity) idx %= p.train_capacity;
+    p.train[idx] = rec;
+  }
+}
+
+// ------------------------------------------------------------------------- generate
+__global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
+  const uint32_t n = p.counters[qin];
+  const uint32_t* q_in = p.queue[qin];
+  uint32_t* q_out = p.queue[qin ^ 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[CNT_SHADOW] = 0u;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t pixel = 0;
+    bool keep = false;
+    if (valid) {
+      pixel = q_in[i];
+      const u4 m = p.st_m[pixel];
+      keep = true;
+      if (!(m.w & kAlive)) {
+        int local = p.started[pixel];
+        if (local > 0) {  // a sample just ended: fold it into the pixel's sum
+          const q4 s = p.st_s[pixel];
+          q4 a = p.acc[pixel];
+          a.x += s.x; a.y += s.y; a.z += s.z;
+          p.acc[pixel] = a;
+        }
+        if (local >= p.sample_count) {
+          keep = false;
+        } else {
+          const int x = (int)(pixel % (uint32_t)p.width), y = (int)(pixel / (uint32_t)p.width);
+          const uint64_t carried = ((uint64_t)m.y << 32) | (uint64_t)m.x;
+          PathState ps;
+          generate_path(p.cam, x, y, hash_sample_index(p, local), p.frame, p.width, p.height,
+                        start_seed(p, pixel, local, carried), ps);
+          store_state(p, pixel, ps);
+          p.started[pixel] = local + 1;
+        }
+      }
+    }
+    const uint32_t slot = wave_append_slot(keep, &p.counters[qin ^ 1]);
+    if (keep) q_out[slot] = pixel;
+  }
+}
+
+// --------------------------------------------------------------------------- extend
+__global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
+  const uint32_t n = p.counters[q];
+  const uint32_t* queue = p.queue[q];
+  LdsStack st = lds_stack();
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.ray_counters[0] += n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t pixel = queue[i];
+    const q4 a = p.st_o[pixel], b = p.st_d[pixel];
+    const Hit h = trace_ray(p.scene, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), 0.0f, 1e16f, false, st, p.stack_depth);
+    p.hits[i] = q4{u2f((uint32_t)h.prim), h.t, h.b1, h.b2};
+  }
+}
+
+// ---------------------------------------------------------------------------- shade
+__global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
+  const uint32_t n = p.counters[q];
+  const uint32_t* queue = p.queue[q];
+  const ShadeParams sp = shade_params(p);
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    ShadowRay sr;
+    sr.valid = false;
+    TrainRec tr;
+    bool want_train = false;
+    uint32_t pixel = 0;
+    if (valid) {
+      pixel = queue[i];
+      PathState ps = load_state(p, pixel);
+      const q4 hq = p.hits[i];
+      const Hit h{(int)f2u(hq.x), hq.y, hq.z, hq.w};
+      RandCtx rc;
+      rc.px = (int)(pixel % (uint32_t)p.width);
+      rc.py = (int)(pixel / (uint32_t)p.width);
+      rc.frame = p.frame;
+      rc.s = ps_dim(ps) < 2u ? hash_sample_index(p, p.started[pixel] - 1) : 0;
+      shade_hit(p.scene, p.guide, sp, rc, ps, h, sr, p.train ? &tr : nullptr, &want_train);
+      store_state(p, pixel, ps);
+    }
+    append_train(p, want_train, tr);
+    const uint32_t slot = wave_append_slot(sr.valid, &p.counters[CNT_SHADOW]);
+    if (sr.valid) {
+      p.sh_o[slot] = q4{sr.o.x, sr.o.y, sr.o.z, sr.tmax};
+      p.sh_d[slot] = q4{sr.d.x, sr.d.y, sr.d.z, u2f(pixel)};
+      p.sh_c[slot] = q4{sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.f};
+    }
+  }
+}
+
+// -------------------------------------------------------------------------- occlude
+__global__ void __launch_bounds__(256) k_occlude(RenderParams p, int qnext_out) {
+  const uint32_t n = p.counters[CNT_SHADOW];
+  LdsStack st = lds_stack();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    p.ray_counters[1] += n;
+    p.counters[qnext_out] = 0u;  // the queue the next generate pass appends to
+  }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const q4 o = p.sh_o[i], d = p.sh_d[i];
+    const Hit h = trace_ray(p.scene, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 0.0f, o.w, true, st, p.stack_depth);
+    if (h.prim < 0) {
+      const uint32_t pixel = f2u(d.w);
+      const q4 c = p.sh_c[i];
+      q4 s = p.st_s[pixel];
+      s.x += c.x; s.y += c.y; s.z += c.z;
+      p.st_s[pixel] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- fused
+__global__ void __launch_bounds__(256) k_bounce(RenderParams p, int qin, int bounces) {
+  const uint32_t n = p.counters[qin];
+  const uint32_t* q_in = p.queue[qin];
+  uint32_t* q_out = p.queue[qin ^ 1];
+  LdsStack st = lds_stack();
+  const ShadeParams sp = shade_params(p);
+  uint32_t rays_rad = 0, rays_sh = 0;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    bool keep = false;
+    uint32_t pixel = 0;
+    if (valid) {
+      pixel = q_in[i];
+      PathState ps = load_state(p, pixel);
+      int local = p.started[pixel];
+      q4 acc = p.acc[pixel];
+      RandCtx rc;
+      rc.px = (int)(pixel % (uint32_t)p.width);
+      rc.py = (int)(pixel / (uint32_t)p.width);
+      rc.frame = p.frame;
+      keep = true;
+      for (int b = 0; b < bounces; ++b) {
+        if (!(ps.flags & kAlive)) {
+          if (local > 0) { acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z; ps.sum = mk3(0.f); }
+          if (local >= p.sample_count) { keep = false; break; }
+          generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, local), p.frame, p.width, p.height,
+                        start_seed(p, pixel, local, ps.seed), ps);
+          local++;
+        }
+        rc.s = hash_sample_index(p, local - 1);
+        const Hit h = trace_ray(p.scene, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth);
+        rays_rad++;
+        ShadowRay sr;
+        TrainRec tr;
+        bool want_train = false;
+        shade_hit(p.scene, p.guide, sp, rc, ps, h, sr, p.train ? &tr : nullptr, &want_train);
+        if (p.train && want_train) {
+          uint32_t idx = atomicAdd(p.train_write_idx, 1u);
+          if (p.train_capacity) idx %= p.train_capacity;
+          p.train[idx] = tr;
+        }
+        if (sr.valid) {
+          rays_sh++;
+          const Hit o = trace_ray(p.scene, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth);
+          if (o.prim < 0) ps.sum += sr.contrib;
+        }
+      }
+      // a path that ended on the last bounce of this launch is folded by the next launch
+      store_state(p, pixel, ps);
+      p.started[pixel] = local;
+      p.acc[pixel] = acc;
+    }
+    const uint32_t slot = wave_append_slot(keep, &p.counters[qin ^ 1]);
+    if (keep) q_out[slot] = pixel;
+  }
+  // ray counters: wave reduction, one 64-bit atomic pair per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    rays_rad += __shfl_down(rays_rad, off);
+    rays_sh += __shfl_down(rays_sh, off);
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    if (rays_rad) atomicAdd(&p.ray_counters[0], (unsigned long long)rays_rad);
+    if (rays_sh) atomicAdd(&p.ray_counters[1], (unsigned long long)rays_sh);
+  }
+}
+// Resets the counter of the queue the NEXT fused launch appends to.
+__global__ void k_reset_counter(uint32_t* counters, int idx) { counters[idx] = 0u; }
+
+// ------------------------------------------------------------------------ utilities
+__global__ void k_iota(uint32_t* dst, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = i;
+}
+__global__ void k_finalize(const q4* acc, const int* started, float* out, uint32_t npx, int mode) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const q4 a = acc[i];
+    if (mode == 0) {
+      const int c = started[i];
+      const float inv = c > 0 ? 1.0f / (float)c : 0.0f;
+      out[3 * i + 0] = a.x * inv; out[3 * i + 1] = a.y * inv; out[3 * i + 2] = a.z * inv;
+    } else {
+      out[3 * i + 0] += a.x; out[3 * i + 1] += a.y; out[3 * i + 2] += a.z;
+    }
+  }
+}
+// optix_device.cu:944,990-997,1069: the mosaic value is the CFA channel of the pixel's mean, clamped at 0
+__global__ void k_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float inv_div) {
+  const uint32_t npx = (uint32_t)w * (uint32_t)h;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const int x = (int)(i % (uint32_t)w), y = (int)(i / (uint32_t)w);
+    const int ch = bayer_channel_for(x, y, pattern);
+    raw[i] = fmaxf(rgb[3 * i + ch] * inv_div, 0.f);
+  }
+}
+
+static inline size_t stack_bytes(const RenderParams& p, const LaunchCfg& c) {
+  return (size_t)c.threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry);
+}
+
+void launch_generate(const RenderParams& p, int qin, const LaunchCfg& c) {
+  k_generate<<<c.blocks, c.threads, 0, c.stream>>>(p, qin);
+  PT_KCHECK();
+}
+void launch_extend(const RenderParams& p, int q, const LaunchCfg& c) {
+  k_extend<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
+  PT_KCHECK();
+}
+void launch_shade(const RenderParams& p, int q, const LaunchCfg& c) {
+  k_shade<<<c.blocks, c.threads, 0, c.stream>>>(p, q);
+  PT_KCHECK();
+}
+void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c) {
+  k_occlude<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qnext_out);
+  PT_KCHECK();
+}
+void launch_bounce(const RenderParams& p, int qin, int bounces, const LaunchCfg& c) {
+  k_bounce<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qin, bounces);
+  PT_KCHECK();
+  k_reset_counter<<<1, 1, 0, c.stream>>>(p.counters, qin);  // qin is the next launch's output queue
+  PT_KCHECK();
+}
+void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {
+  k_iota<<<1024, 256, 0, s>>>(dst, n);
+  PT_KCHECK();
+}
+void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int mode, hipStream_t s) {
+  k_finalize<<<1024, 256, 0, s>>>(acc, started, out_rgb, npx, mode);
+  PT_KCHECK();
+}
+void launch_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float divisor, hipStream_t s) {
+  k_mosaic<<<1024, 256, 0, s>>>(rgb, raw, w, h, pattern, 1.0f / divisor);
+  PT_KCHECK();
+}
+
+// ----------------------------------------------------------------- stage-level debug
+__global__ void k_dbg_pcg(unsigned long long seed, int n, uint32_t* out_u, float* out_f) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint64_t s = seed, s2 = seed;
+  for (int i = 0; i < n; ++i) {
+    out_u[i] = pcg(s);
+    out_f[i] = rnd(s2);
+  }
+}
+__global__ void k_dbg_blue_noise(int n, const int* xysf, float* uv, float* jitter) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float u, v;
+  blue_noise(xysf[4 * i], xysf[4 * i + 1], xysf[4 * i + 2], xysf[4 * i + 3], u, v);
+  uv[2 * i] = u; uv[2 * i + 1] = v;
+  jitter[2 * i] = sample_tri(u); jitter[2 * i + 1] = sample_tri(v);
+}
+__global__ void k_dbg_camera(CameraView cam, int w, int h, int n, const int* xy, const float* jitter, float* dirs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f3 d = camera_dir(cam, xy[2 * i], xy[2 * i + 1], jitter[2 * i], jitter[2 * i + 1], w, h);
+  dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+}
+__global__ void __launch_bounds__(256) k_trace_rays(SceneView sc, int stack_depth, int n, const float* o, const float* d,
+                                                    const float* tmin, const float* tmax, int any_hit, int* prim,
+                                                    float* t, float* b1, float* b2) {
+  LdsStack st = lds_stack();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const Hit h = trace_ray(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                            tmin[i], tmax[i], any_hit != 0, st, stack_depth);
+    if (any_hit) {
+      prim[i] = h.prim >= 0 ? 1 : 0;
+    } else {
+      prim[i] = h.prim;
+      t[i] = h.t; b1[i] = h.b1; b2[i] = h.b2;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_dbg_shade(SceneView sc, GuideView gv, int guiding, int stack_depth, int n,
+                                                   DbgPathRec* recs, const int* prim, const float* b1, const float* b2,
+                                                   int frame, int max_depth, int* shadow_traced) {
+  LdsStack st = lds_stack();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    DbgPathRec r = recs[i];
+    PathState ps;
+    ps.o = mk3(r.origin[0], r.origin[1], r.origin[2]);
+    ps.d = mk3(r.direction[0], r.direction[1], r.direction[2]);
+    ps.T = mk3(r.throughput[0], r.throughput[1], r.throughput[2]);
+    ps.sum = mk3(0.f);
+    ps.seed = r.seed;
+    ps.prev_pdf = r.prev_pdf_bsdf;
+    const uint32_t dim = r.rng_dim < 2 ? (uint32_t)r.rng_dim : 2u;
+    ps.flags = ((uint32_t)r.depth & kDepthMask) | (dim << kDimShift) | (r.prev_pdf_valid ? kPrevValid : 0u) | kAlive;
+    const RandCtx rc{r.px, r.py, r.sample, frame};
+    const Hit h{prim[i], 0.f, b1[i], b2[i]};
+    ShadowRay sr;
+    const ShadeParams sp{frame, max_depth, guiding};
+    shade_hit(sc, gv, sp, rc, ps, h, sr, nullptr, nullptr);
+    if (sr.valid) {
+      const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, stack_depth);
+      if (o.prim < 0) ps.sum += sr.contrib;
+    }
+    shadow_traced[i] = sr.valid ? 1 : 0;
+    // radiance slot returns the bounce's contribution radiance * throughput
+    r.radiance[0] = ps.sum.x; r.radiance[1] = ps.sum.y; r.radiance[2] = ps.sum.z;
+    r.throughput[0] = ps.T.x; r.throughput[1] = ps.T.y; r.throughput[2] = ps.T.z;
+    r.origin[0] = ps.o.x; r.origin[1] = ps.o.y; r.origin[2] = ps.o.z;
+    r.direction[0] = ps.d.x; r.direction[1] = ps.d.y; r.direction[2] = ps.d.z;
+    r.seed = ps.seed;
+    r.depth = (int)ps_depth(ps);
+    r.done = (ps.flags & kAlive) ? 0 : 1;
+    r.prev_pdf_bsdf = ps.prev_pdf;
+    r.prev_pdf_valid = (ps.flags & kPrevValid) ? 1 : 0;
+    r.rng_dim = (int)ps_dim(ps);
+    recs[i] = r;
+  }
+}
+__global__ void k_dbg_guiding(GuideView gv, int n, const float* pos, const float* u3, const float* wi, int* region,
+                              int* lobe, float* dir, float* pdf_dir, float* pdf_wi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f3 P = mk3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]);
+  const f3 w = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+  const int rid = guiding_region_id(gv, P);
+  region[i] = rid;
+  lobe[i] = -1;
+  dir[3 * i] = dir[3 * i + 1] = dir[3 * i + 2] = 0.f;
+  pdf_dir[i] = pdf_wi[i] = 0.f;
+  if (rid < 0) return;
+  const GuideRegion R = gv.regions[rid];
+  if (R.lobe_num == 0) return;
+  const GuideLobe* L = gv.lobes + R.lobe_ofs;
+  const int li = guiding_choose_lobe(L, R.lobe_num, u3[3 * i]);
+  lobe[i] = li;
+  pdf_wi[i] = guiding_mixture_pdf(L, R.lobe_num, w);
+  if (li < 0) return;
+  const f3 g = vmf_sample(ld3(L[li].mu), L[li].kappa, u3[3 * i + 1], u3[3 * i + 2]);
+  dir[3 * i] = g.x; dir[3 * i + 1] = g.y; dir[3 * i + 2] = g.z;
+  pdf_dir[i] = guiding_mixture_pdf(L, R.lobe_num, g);
+}
+
+void launch_dbg_pcg(unsigned long long seed, int n, uint32_t* out_u, float* out_f, hipStream_t s) {
+  k_dbg_pcg<<<1, 1, 0, s>>>(seed, n, out_u, out_f);
+  PT_KCHECK();
+}
+void launch_dbg_blue_noise(int n, const int* xysf, float* uv, float* jitter, hipStream_t s) {
+  k_dbg_blue_noise<<<(n + 255) / 256, 256, 0, s>>>(n, xysf, uv, jitter);
+  PT_KCHECK();
+}
+void launch_dbg_camera(CameraView cam, int w, int h, int n, const int* xy, const float* jitter, float* dirs, hipStream_t s) {
+  k_dbg_camera<<<(n + 255) / 256, 256, 0, s>>>(cam, w, h, n, xy, jitter, dirs);
+  PT_KCHECK();
+}
+static int blocks_for(int n) {
+  int b = (n + 255) / 256;
+  return b < 1 ? 1 : (b > 2048 ? 2048 : b);
+}
+void launch_trace_rays(SceneView sc, int stack_depth, int n, const float* o, const float* d, const float* tmin,
+                       const float* tmax, int any_hit, int* prim, float* t, float* b1, float* b2, hipStream_t s) {
+  const size_t lds = 256 * (size_t)(stack_depth > 0 ? stack_depth : 1) * sizeof(StackEntry);
+  k_trace_rays<<<blocks_for(n), 256, lds, s>>>(sc, stack_depth, n, o, d, tmin, tmax, any_hit, prim, t, b1, b2);
+  PT_KCHECK();
+}
+void launch_dbg_shade(SceneView sc, GuideView gv, int guiding, int stack_depth, int n, DbgPathRec* recs, const int* prim,
+                      const float* b1, const float* b2, int frame, int max_depth, int* shadow_traced, hipStream_t s) {
+  const size_t lds = 256 * (size_t)(stack_depth > 0 ? stack_depth : 1) * sizeof(StackEntry);
+  k_dbg_shade<<<blocks_for(n), 256, lds, s>>>(sc, gv, guiding, stack_depth, n, recs, prim, b1, b2, frame, max_depth,
+                                              shadow_traced);
+  PT_KCHECK();
+}
+void launch_dbg_guiding(GuideView gv, int n, const float* pos, const float* u3, const float* wi, int* region, int* lobe,
+                        float* dir, float* pdf_dir, float* pdf_wi, hipStream_t s) {
+  k_dbg_guiding<<<(n + 255) / 256, 256, 0, s>>>(gv, n, pos, u3, wi, region, lobe, dir, pdf_dir, pdf_wi);
+  PT_KCHECK();
+}
+
+}  // namespace pt

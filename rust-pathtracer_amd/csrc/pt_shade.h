@@ -1,0 +1,346 @@
+// pt_shade.h -- path state and the shading step of the integrator (a6, a8, a9).
+//
+// One call of shade_hit() is one execution of the reference's closest-hit program
+// (optix_device.cu:400-673) or radiance-miss program (370-375) followed by raygen's
+// "accumulate radiance * throughput" (988-997): the contribution of a bounce is weighted
+// with the throughput AFTER the bounce's BSDF sampling and Russian roulette.
+#pragma once
+#include "pt_bvh.h"
+#include "pt_guiding.h"
+#include "pt_rng.h"
+#include "pt_types.h"
+
+namespace pt {
+
+// Register image of one path.  In HBM it is four 16-byte SoA streams:
+//   {o.xyz, T.x} {d.xyz, T.y} {sum.xyz, T.z} {seed_lo, seed_hi, prev_pdf, flags}
+struct PathState {
+  f3 o, d, T, sum;
+  uint64_t seed;
+  float prev_pdf;
+  uint32_t flags;
+};
+constexpr uint32_t kDepthMask = 0xffu;
+constexpr uint32_t kDimShift = 8u, kDimMask = 3u << 8;
+constexpr uint32_t kPrevValid = 1u << 10;
+constexpr uint32_t kAlive = 1u << 11;
+
+PT_HD uint32_t ps_depth(const PathState& p) { return p.flags & kDepthMask; }
+PT_HD uint32_t ps_dim(const PathState& p) { return (p.flags & kDimMask) >> kDimShift; }
+
+struct ShadeParams {
+  int frame;
+  int max_depth;
+  int guiding;  // 0/1: GuideView valid
+};
+
+// The next-event shadow ray a shading step wants traced; contrib = Lo * T (already weighted),
+// added to the path's sample sum when the ray is unoccluded.
+struct ShadowRay {
+  f3 o, d;
+  float tmax;
+  f3 contrib;
+  bool valid;
+};
+
+struct RandCtx {
+  int px, py, s, frame;
+};
+
+// optix_device.cu:198-209: the first two dimensions of a path reuse the blue-noise pair
+// that jittered the pixel; every later draw is PCG.
+PT_HD float next_rand(PathState& ps, const RandCtx& rc) {
+  const uint32_t dim = ps_dim(ps);
+  if (dim < 2u) {
+    float u, v;
+    blue_noise(rc.px, rc.py, rc.s, rc.frame, u, v);
+    ps.flags += 1u << kDimShift;
+    return dim == 0u ? u : v;
+  }
+  return rnd(ps.seed);
+}
+
+// optix_device.cu:275-278 with F0 grey: returns the scalar Schlick term
+PT_HD float schlick(float cosTheta, float f0) { return f0 + (1.0f - f0) * pow5(fmaxf(0.0f, 1.0f - cosTheta)); }
+
+PT_HD f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(i, n)); }
+
+// optix_device.cu:285-332
+PT_HD void sample_ggx_vndf(float ux, float uy, float alpha, f3 N, f3 V, f3& L, f3& H, float& pdf) {
+  f3 T, B;
+  make_onb(N, T, B);
+  const f3 Vlocal = mk3(dot(V, T), dot(V, B), dot(V, N));
+  const f3 Vh = normalize_chk(mk3(alpha * Vlocal.x, alpha * Vlocal.y, Vlocal.z));
+  const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+  const f3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * rsqrt(lensq) : mk3(1.0f, 0.0f, 0.0f);
+  const f3 T2 = cross(Vh, T1);
+  const float r = fsqrt(ux);
+  const float t1 = r * cos2pi(uy);
+  float t2 = r * sin2pi(uy);
+  const float s = 0.5f * (1.0f + Vh.z);
+  t2 = (1.0f - s) * fsqrt(fmaxf(0.0f, 1.0f - t1 * t1)) + s * t2;
+  const f3 Nh = T1 * t1 + T2 * t2 + Vh * fsqrt(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
+  const f3 Hlocal = normalize_chk(mk3(alpha * Nh.x, alpha * Nh.y, fmaxf(0.0f, Nh.z)));
+  H = normalize_chk(T * Hlocal.x + B * Hlocal.y + N * Hlocal.z);
+  L = normalize_chk(reflect(-V, H));
+  const float NoH = fmaxf(dot(N, H), 0.0f);
+  const float NoV = fmaxf(dot(N, V), 0.0f);
+  const float VoH = fmaxf(dot(V, H), 0.0f);
+  const float alpha2 = alpha * alpha;
+  const float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
+  const float D = alpha2 * rcp(kPi * denom * denom);
+  const float G1V = 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
+  pdf = (D * NoH * G1V) * rcp(4.0f * fmaxf(VoH, 1e-6f));
+}
+
+// optix_device.cu:660-672 (== 468-480).  Returns false when the path ends here.
+PT_HD bool depth_and_roulette(PathState& ps, const RandCtx& rc, int max_depth) {
+  ps.flags += 1u;  // depth++
+  const int depth = (int)ps_depth(ps);
+  if (depth >= max_depth) return false;
+  if (depth >= max_depth - 2) {
+    const float p = max3(ps.T);
+    if (next_rand(ps, rc) > p) return false;
+    ps.T = ps.T * rcp(fmaxf(p, 1e-3f));
+  }
+  return true;
+}
+
+// One bounce.  hit.prim < 0 is the radiance miss (optix_device.cu:370-375).
+// train, when non-null, receives the guiding training record of this vertex and
+// *want_train is set (the caller appends it to the ring, optix_device.cu:431-441).
+PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams& sp, const RandCtx& rc,
+                     PathState& ps, const Hit& hit, ShadowRay& sr, TrainRec* train, bool* want_train) {
+  sr.valid = false;
+  if (want_train) *want_train = false;
+  if (hit.prim < 0) {
+    ps.flags &= ~kAlive;  // radiance = 0, done = 1: nothing to add
+    return;
+  }
+  // optix_device.cu:404-429: geometry and material of the primitive
+  const q4* rec = reinterpret_cast<const q4*>(sc.shade + hit.prim);
+  const q4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
+  const f3 v0 = ldv(r0), v1 = ldv(r1), v2 = ldv(r2);
+  const float Roughness = r0.w, IOR = r1.w, Transmission = r2.w;
+  const float b1 = hit.b1, b2 = hit.b2, b0 = 1.0f - b1 - b2;
+  const f3 P = v0 * b0 + v1 * b1 + v2 * b2;
+  const f3 Ng = ldv(r3);
+  const f3 Base_colour = ldv(r4), Emission = ldv(r5);
+  const f3 dir = ps.d;
+
+  const bool is_delta = (Transmission > 0.0f) || (Roughness <= 0.0f);
+  if (!is_delta && train) {
+    train->position[0] = P.x; train->position[1] = P.y; train->position[2] = P.z;
+    train->dir_in[0] = -dir.x; train->dir_in[1] = -dir.y; train->dir_in[2] = -dir.z;
+    train->contrib[0] = ps.T.x; train->contrib[1] = ps.T.y; train->contrib[2] = ps.T.z;
+    train->is_delta = 0u;
+    *want_train = true;
+  }
+
+  f3 radiance;
+  if (Transmission > 0.0f) {
+    // optix_device.cu:443-482: smooth dielectric, Schlick Fresnel
+    const bool entering = dot(dir, Ng) < 0.0f;
+    const f3 N = entering ? Ng : -Ng;
+    const float eta = entering ? rcp(IOR) : IOR;
+    const float cosi = fmaxf(dot(-N, dir), 0.0f);
+    float f0 = (IOR - 1.0f) * rcp(IOR + 1.0f);
+    f0 = f0 * f0;
+    const float Fr = f0 + (1.0f - f0) * pow5(1.0f - cosi);
+    bool do_reflect = next_rand(ps, rc) < Fr;
+    f3 Tdir = mk3(0.f);
+    if (!do_reflect) {
+      // optix_device.cu:266-273
+      const float ci = dot(-N, dir);
+      const float k = 1.0f - eta * eta * (1.0f - ci * ci);
+      if (k < 0.0f) {
+        do_reflect = true;
+      } else {
+        Tdir = dir * eta + N * (eta * ci - fsqrt(k));
+      }
+    }
+    if (do_reflect) {
+      ps.o = P + N * 1e-3f;
+      ps.d = reflect(dir, N);
+    } else {
+      ps.o = P - N * 1e-3f;
+      ps.d = normalize3(Tdir);
+      ps.T = ps.T * Base_colour;
+    }
+    radiance = Emission;
+    ps.flags &= ~kPrevValid;
+    ps.prev_pdf = 0.0f;
+  } else {
+    // optix_device.cu:484-492
+    float f0 = (IOR - 1.0f) * rcp(IOR + 1.0f);
+    f0 = f0 * f0;
+    const f3 V = -dir;
+    const float NoV = fmaxf(dot(Ng, V), 0.0f);
+    const float F = schlick(NoV, f0);
+    const float spec_prob = fminf(0.99f, fmaxf(0.01f, (F + F + F) * (1.0f / 3.0f)));
+    const float diff_prob = 1.0f - spec_prob;
+    const f3 kd = Base_colour * (1.0f - F);
+    const float alpha = fmaxf(Roughness * Roughness, 1e-4f);
+    const float alpha2 = alpha * alpha;
+    const float area = 4.0f * sc.light_half[0] * sc.light_half[1];
+    const f3 light_n = ld3(sc.light_normal);
+
+    // optix_device.cu:495-548: next-event estimation towards the rectangle light
+    f3 Lo = mk3(0.0f);
+    {
+      const float u = (next_rand(ps, rc) * 2.0f - 1.0f) * sc.light_half[0];
+      const float v = (next_rand(ps, rc) * 2.0f - 1.0f) * sc.light_half[1];
+      const f3 lp = mk3(sc.light_pos[0] + u, sc.light_pos[1] + v, sc.light_pos[2]);
+      const f3 L = lp - P;
+      const float dist2 = fmaxf(dot(L, L), 1e-6f);
+      const float dist = fsqrt(dist2);
+      const f3 wi = L * rcp(dist);
+      const float cosS = fmaxf(0.0f, dot(Ng, wi));
+      const float cosL = fmaxf(0.0f, dot(light_n, -wi));
+      if (cosS > 0.0f && cosL > 0.0f) {
+        const f3 H = normalize3(V + wi);
+        const float VoH = fmaxf(dot(V, H), 0.0f);
+        const float NoH = fmaxf(dot(Ng, H), 0.0f);
+        const float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
+        const float D = alpha2 * rcp(kPi * denom * denom);
+        const float G1V = 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
+        const float G1L = 2.0f * cosS * rcp(cosS + fsqrt(alpha2 + (1.0f - alpha2) * cosS * cosS));
+        const float Fh = schlick(VoH, f0);
+        const float f_spec = Fh * (D * G1V * G1L * rcp(fmaxf(4.0f * NoV * cosS, 1e-6f)));
+        const float pdf_spec = D * NoH * G1V * rcp(fmaxf(4.0f * VoH, 1e-6f)) * spec_prob;
+        const float pdf_diff = cosS * kInvPi * diff_prob;
+        const float pdf_bsdf = pdf_spec + pdf_diff;
+        const float pdf_area = rcp(area);
+        const float pdf_light = pdf_area * dist2 * rcp(cosL);
+        const float w = pdf_light * rcp(pdf_light + pdf_bsdf);
+        const f3 f = kd * kInvPi + mk3(f_spec);
+        const f3 contrib = ld3(sc.light_emit) * f * (cosS * cosL * rcp(dist2)) * area;
+        Lo = contrib * w;
+        sr.valid = true;
+        sr.o = P + Ng * 1e-3f;
+        sr.d = wi;
+        sr.tmax = dist - 1e-3f;
+      }
+    }
+
+    // optix_device.cu:551-561: emitted light, MIS-weighted against the previous bounce's pdf
+    f3 emission = Emission;
+    if ((ps.flags & kPrevValid) && (Emission.x > 0.0f || Emission.y > 0.0f || Emission.z > 0.0f)) {
+      const f3 L = P - ps.o;
+      const float dist2 = fmaxf(dot(L, L), 1e-6f);
+      const float cosL = fmaxf(0.0f, dot(light_n, -dir));
+      const float pdf_light = dist2 / (cosL * area);
+      const float w_bsdf = ps.prev_pdf / (ps.prev_pdf + pdf_light);
+      emission = emission * w_bsdf;
+    }
+    radiance = emission;
+
+    const float choose = next_rand(ps, rc);
+    if (choose < spec_prob) {
+      // optix_device.cu:564-589
+      const float ux = next_rand(ps, rc);
+      const float uy = next_rand(ps, rc);
+      f3 newDir, H;
+      float pdf;
+      sample_ggx_vndf(ux, uy, alpha, Ng, V, newDir, H, pdf);
+      const float NoL = fmaxf(dot(Ng, newDir), 0.0f);
+      const float VoH = fmaxf(dot(V, H), 0.0f);
+      const float NoH = fmaxf(dot(Ng, H), 0.0f);
+      const float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
+      const float D = alpha2 * rcp(kPi * denom * denom);
+      const float G1V = 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
+      const float G1L = 2.0f * NoL * rcp(NoL + fsqrt(alpha2 + (1.0f - alpha2) * NoL * NoL));
+      const float Fh = schlick(VoH, f0);
+      const float spec_brdf = Fh * (D * G1V * G1L * rcp(fmaxf(4.0f * NoV * NoL, 1e-6f)));
+      ps.o = P + Ng * 1e-3f;
+      ps.d = newDir;
+      ps.T = ps.T * (spec_brdf * NoL * rcp(fmaxf(pdf * spec_prob, 1e-6f)));
+      ps.prev_pdf = pdf * spec_prob;
+      ps.flags |= kPrevValid;
+    } else {
+      // optix_device.cu:590-658: diffuse lobe, optionally guided
+      f3 newDir = mk3(0.f);
+      float cosTheta = 0.f, p_guided = 0.f, p_bsdf = 0.f;
+      f3 lobe_rgb = mk3(1.0f);
+      const GuideLobe* lobes = nullptr;
+      uint32_t lobe_num = 0;
+      bool have_guiding = false;
+      if (sp.guiding) {
+        const int region_id = guiding_region_id(gv, P);
+        if (region_id >= 0) {
+          const GuideRegion R = gv.regions[region_id];
+          if (R.lobe_num > 0) {
+            lobes = gv.lobes + R.lobe_ofs;
+            lobe_num = R.lobe_num;
+            have_guiding = true;
+          }
+        }
+      }
+      bool used_guiding = false;
+      if (have_guiding) {
+        const int lobe_idx = guiding_choose_lobe(lobes, lobe_num, next_rand(ps, rc));
+        if (lobe_idx >= 0) {
+          const float ux = next_rand(ps, rc);
+          const float uy = next_rand(ps, rc);
+          const GuideLobe lb = lobes[lobe_idx];
+          const f3 gdir = vmf_sample(ld3(lb.mu), lb.kappa, ux, uy);
+          const float cosG = fmaxf(dot(gdir, Ng), 0.0f);
+          const float p_g = guiding_mixture_pdf(lobes, lobe_num, gdir);
+          const float p_b = cosG * kInvPi;
+          const float ch2 = next_rand(ps, rc) * (p_g + p_b);
+          if (ch2 < p_g) {
+            used_guiding = true;
+            newDir = gdir; cosTheta = cosG; p_guided = p_g; p_bsdf = p_b;
+            lobe_rgb = ld3(lb.rgb);
+          }
+        }
+      }
+      if (!used_guiding) {
+        const float r1 = next_rand(ps, rc);
+        const float r2 = next_rand(ps, rc);
+        cosTheta = fsqrt(1.0f - r2);
+        const float sinTheta = fsqrt(r2);
+        const f3 local = mk3(cos2pi(r1) * sinTheta, sin2pi(r1) * sinTheta, cosTheta);
+        f3 tangent, bitangent;
+        make_onb(Ng, tangent, bitangent);
+        newDir = normalize_chk(tangent * local.x + bitangent * local.y + Ng * local.z);
+        p_bsdf = cosTheta * kInvPi;
+        if (have_guiding) p_guided = guiding_mixture_pdf(lobes, lobe_num, newDir);
+      }
+      ps.o = P + Ng * 1e-3f;
+      ps.d = newDir;
+      const float final_pdf = used_guiding ? p_guided : p_bsdf;
+      f3 T = ps.T * kd;
+      if (used_guiding) T = T * lobe_rgb;
+      ps.T = T * (cosTheta / (kPi * final_pdf * diff_prob));
+      ps.prev_pdf = final_pdf * diff_prob;
+      ps.flags |= kPrevValid;
+    }
+    // NEE contribution is weighted below, once the post-bounce throughput is known
+    if (sr.valid) sr.contrib = Lo;
+  }
+
+  if (!depth_and_roulette(ps, rc, sp.max_depth)) ps.flags &= ~kAlive;
+
+  // optix_device.cu:988-989: contribution = radiance * throughput (post-bounce)
+  ps.sum += radiance * ps.T;
+  if (sr.valid) sr.contrib = sr.contrib * ps.T;
+}
+
+// optix_device.cu:955-969: start sample `s` of pixel (x,y).  The caller supplies the PCG
+// state the sample starts from.
+PT_HD void generate_path(const CameraView& cam, int x, int y, int s, int frame, int width, int height, uint64_t seed,
+                         PathState& ps) {
+  float u, v;
+  blue_noise(x, y, s, frame, u, v);
+  const float jx = sample_tri(u), jy = sample_tri(v);  // optix_device.cu:192-196
+  ps.o = ld3(cam.eye);
+  ps.d = camera_dir(cam, x, y, jx, jy, width, height);
+  ps.T = mk3(1.0f);
+  ps.sum = mk3(0.0f);
+  ps.seed = seed;
+  ps.prev_pdf = 0.0f;
+  ps.flags = kAlive;
+}
+
+}  // namespace pt

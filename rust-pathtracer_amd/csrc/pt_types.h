@@ -1,0 +1,194 @@
+// pt_types.h -- vector type, math wrappers and shared POD layouts for the gfx950 kernels.
+//
+// The integrator's device functions are written against this header only, so the same
+// sources also compile with a host C++ compiler for CPU-side debugging of the device
+// logic (tests/hostcheck); the shipped library never runs them on the CPU.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PT_HD __host__ __device__ __forceinline__
+#define PT_D __device__ __forceinline__
+#else
+#define PT_HD inline
+#define PT_D inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__
+#define PT_ON_DEVICE 1
+#else
+#define PT_ON_DEVICE 0
+#endif
+
+namespace pt {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 1.0f / kPi;
+
+struct f3 {
+  float x, y, z;
+};
+PT_HD f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+PT_HD f3 mk3(float s) { return f3{s, s, s}; }
+PT_HD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PT_HD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PT_HD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+PT_HD f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+PT_HD f3 operator*(float s, f3 a) { return f3{a.x * s, a.y * s, a.z * s}; }
+PT_HD f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+PT_HD f3& operator+=(f3& a, f3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+PT_HD float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_HD f3 cross(f3 a, f3 b) { return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+PT_HD float comp(f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+PT_HD float max3(f3 v) { return fmaxf(v.x, fmaxf(v.y, v.z)); }
+
+// ---- fast scalar math: one hardware instruction each on gfx950 (v_rcp/v_sqrt/v_rsq/
+// v_sin/v_cos/v_exp/v_log, all about 1 ulp), libm on the host.  The reference itself is
+// built with --use_fast_math (optix/CMakeLists.txt:60,78), so approximate transcendental
+// rates are the intended precision class.
+PT_HD float rcp(float x) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+PT_HD float fsqrt(float x) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_sqrtf(x);
+#else
+  return sqrtf(x);
+#endif
+}
+PT_HD float rsqrt(float x) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+// sin/cos of 2*pi*u: v_sin_f32/v_cos_f32 take their argument in revolutions.
+PT_HD float sin2pi(float u) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_sinf(u);
+#else
+  return sinf(2.0f * kPi * u);
+#endif
+}
+PT_HD float cos2pi(float u) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_cosf(u);
+#else
+  return cosf(2.0f * kPi * u);
+#endif
+}
+PT_HD float fexp(float x) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+#else
+  return expf(x);
+#endif
+}
+PT_HD float flog(float x) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
+#else
+  return logf(x);
+#endif
+}
+PT_HD float pow5(float x) {
+  float x2 = x * x;
+  return x2 * x2 * x;
+}
+PT_HD float fract_pos(float x) { return x - floorf(x); }  // == fmodf(x,1) for x >= 0
+PT_HD float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+PT_HD float length(f3 v) { return fsqrt(dot(v, v)); }
+// optix_device.cu:122-125
+PT_HD f3 normalize_chk(f3 v) {
+  float l2 = dot(v, v);
+  return l2 > 0.f ? v * rsqrt(l2) : mk3(0.f);
+}
+// optix_device.cu:137-139
+PT_HD f3 normalize3(f3 v) { return v * rcp(fmaxf(length(v), 1e-20f)); }
+
+PT_HD uint32_t f2u(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+PT_HD float u2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// ---------------------------------------------------------------------------------
+// Shared POD layouts (host builds them, kernels read them).
+
+// 16-byte vector for coalesced dwordx4 traffic.
+struct alignas(16) q4 {
+  float x, y, z, w;
+};
+struct alignas(16) u4 {
+  uint32_t x, y, z, w;
+};
+
+// Compressed 8-wide BVH node, 80 bytes (layout after Ylitie, Karras, Laine 2017):
+// child boxes are 8-bit offsets on a per-node grid p + q * 2^e.
+struct alignas(16) BvhNode {
+  float px, py, pz;        // grid origin = node box minimum
+  uint8_t ex, ey, ez;      // biased float exponents of the grid step per axis
+  uint8_t imask;           // bit s set: slot s holds an internal child
+  uint32_t child_base;     // index of the first internal child (children contiguous in slot order)
+  uint32_t tri_base;       // index of the first triangle referenced by this node's leaf slots
+  uint8_t meta[8];         // per slot: 0 empty; internal (1<<5)|(24+slot); leaf (unary count<<5)|first triangle offset
+  uint8_t qlox[8], qloy[8], qloz[8];
+  uint8_t qhix[8], qhiy[8], qhiz[8];
+};
+static_assert(sizeof(BvhNode) == 80, "BvhNode must be 80 bytes");
+
+// Per-triangle shading record, indexed by the scene's primitive index (96 bytes).
+struct alignas(16) ShadeRec {
+  float v0[3]; float roughness;
+  float v1[3]; float ior;
+  float v2[3]; float transmission;
+  float ng[3]; float pad0;
+  float base[3]; float pad1;
+  float emission[3]; float pad2;
+};
+static_assert(sizeof(ShadeRec) == 96, "ShadeRec must be 96 bytes");
+
+// optix/guiding_gpu.cuh:8-17
+struct GuideRegion { float bmin[3]; float bmax[3]; uint32_t lobe_ofs, lobe_num; };
+struct GuideLobe { float mu[3]; float kappa; float weight; float rgb[3]; };
+// optix/guiding_gpu.cuh:24-29
+struct TrainRec { float position[3]; float dir_in[3]; float contrib[3]; uint32_t is_delta; };
+
+// Device view of the guiding field (optix/guiding_gpu.cuh:18-22).
+struct GuideView {
+  const GuideRegion* regions;
+  const GuideLobe* lobes;
+  const uint32_t* grid;
+  int res[3];
+  float gmin[3];
+  float cell[3];
+};
+
+struct SceneView {
+  const BvhNode* nodes;
+  const q4* tris;            // 3 x q4 per triangle in BVH leaf order; tris[3i].w carries the primitive index bits
+  const ShadeRec* shade;     // per primitive
+  uint32_t num_tris;
+  // rectangle light used for next-event estimation (optix_wrapper.cpp:842-845)
+  float light_pos[3], light_emit[3], light_normal[3], light_half[2];
+};
+
+struct CameraView {
+  float eye[3], u[3], v[3], w[3];
+};
+
+}  // namespace pt

@@ -1,0 +1,752 @@
+// renderer.cpp -- host runtime and exported C ABI of libpt_hip.so.
+//
+// Mirrors the responsibilities of the reference's wrapper (optix/optix_wrapper.cpp): a lazily
+// created singleton renderer per resolution, the built-in scene and camera, the render
+// entry points and the guiding upload/readback calls -- with the OptiX pipeline replaced by
+// the HIP wavefront kernels of pt_kernels.hip.
+#include "renderer.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace pt {
+namespace {
+
+// ---- global settings (the reference keeps the same kind of file-scope state:
+// optix_wrapper.cpp:147-149, 923-925)
+State* g_handle = nullptr;
+int g_last_w = 0, g_last_h = 0;
+int g_frame = 0;           // Params.frame of the most recent render call
+bool g_frame_pinned = false;
+int g_mode = -1;           // -1: read PT_MODE on first use
+int g_pipeline = -1;       // -1: read PT_PIPELINE on first use
+int g_device = -1;         // -1: read PT_DEVICE on first use
+int g_guiding_enabled = 0;
+uint32_t g_train_capacity = 0;
+int g_grid_res[3] = {0, 0, 0};
+std::vector<pgl_region> g_snap_regions;
+std::vector<pgl_lobe> g_snap_lobes;
+uint64_t g_snap_version = 0;
+HostScene g_scene;
+bool g_scene_init = false;
+uint64_t g_scene_version = 1;
+int g_timing_every = 0;
+KernelStat g_kstats[PT_K_COUNT];
+uint64_t g_rays_total[2] = {0, 0};
+int g_fused_bounces = 8;
+
+int env_choice(const char* name, const char* a, const char* b, int dflt) {
+  const char* v = getenv(name);
+  if (!v) return dflt;
+  if (!strcmp(v, a)) return 0;
+  if (!strcmp(v, b)) return 1;
+  return dflt;
+}
+int mode() {
+  if (g_mode < 0) g_mode = env_choice("PT_MODE", "strict", "converge", PT_MODE_CONVERGE);
+  return g_mode;
+}
+int pipeline() {
+  if (g_pipeline < 0) g_pipeline = env_choice("PT_PIPELINE", "staged", "fused", PT_PIPELINE_FUSED);
+  return g_pipeline;
+}
+int device_index() {
+  if (g_device < 0) {
+    const char* v = getenv("PT_DEVICE");
+    g_device = v ? atoi(v) : 0;
+  }
+  return g_device;
+}
+HostScene& scene() {
+  if (!g_scene_init) {
+    g_scene = make_cornell();
+    g_scene_init = true;
+  }
+  return g_scene;
+}
+
+template <typename T>
+T* dev_alloc(size_t n) {
+  T* p = nullptr;
+  HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)));
+  return p;
+}
+template <typename T>
+void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+template <typename T>
+void upload(T*& d, const std::vector<T>& h) {
+  dev_free(d);
+  d = dev_alloc<T>(h.size());
+  if (!h.empty()) HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+}
+
+// optix_wrapper.cpp:949-976 (and 813-833)
+void set_camera(State& s, const float eye[3], const float lookat[3], const float up[3], float vfov_deg) {
+  auto norm = [](float v[3]) {
+    float len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (len <= 0.f) { v[0] = v[1] = v[2] = 0.f; return; }
+    float inv = 1.0f / len;
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  };
+  auto cross = [](const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  float W[3] = {lookat[0] - eye[0], lookat[1] - eye[1], lookat[2] - eye[2]};
+  norm(W);
+  float U[3];
+  cross(W, up, U);
+  norm(U);
+  float V[3];
+  cross(U, W, V);
+  const float fovY = vfov_deg * float(M_PI) / 180.0f;
+  const float aspect = (s.height == 0) ? 1.f : float(s.width) / float(s.height);
+  const float th = std::tan(fovY * 0.5f);
+  for (int k = 0; k < 3; ++k) {
+    s.cam.eye[k] = eye[k];
+    s.cam.w[k] = W[k];
+    s.cam.u[k] = th * aspect * U[k];
+    s.cam.v[k] = th * V[k];
+  }
+}
+
+void upload_scene(State& s) {
+  HostScene& hs = scene();
+  const int nt = hs.num_tris();
+  BvhBuildResult bvh = build_bvh8(hs.vertices.data(), hs.indices.data(), nt);
+  std::vector<ShadeRec> recs((size_t)std::max(nt, 1));
+  memset(recs.data(), 0, recs.size() * sizeof(ShadeRec));
+  for (int i = 0; i < nt; ++i) {
+    ShadeRec& r = recs[(size_t)i];
+    const Material& m = hs.materials[(size_t)i];
+    for (int k = 0; k < 3; ++k) {
+      r.v0[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + 0] + k];
+      r.v1[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + 1] + k];
+      r.v2[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + 2] + k];
+      r.base[k] = m.base[k];
+      r.emission[k] = m.emission[k];
+    }
+    // optix_device.cu:421: Ng = normalize3(normals[prim]), hoisted to upload time
+    const float* n = &hs.normals[3 * (size_t)i];
+    const float len = std::max(std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-20f);
+    const float inv = 1.0f / len;
+    for (int k = 0; k < 3; ++k) r.ng[k] = n[k] * inv;
+    r.roughness = m.roughness;
+    r.ior = m.ior;
+    r.transmission = m.transmission;
+  }
+  upload(s.d_nodes, bvh.nodes);
+  upload(s.d_tris, bvh.tris);
+  upload(s.d_shade, recs);
+  s.scene.nodes = s.d_nodes;
+  s.scene.tris = s.d_tris;
+  s.scene.shade = s.d_shade;
+  s.scene.num_tris = (uint32_t)nt;
+  for (int k = 0; k < 3; ++k) {
+    s.scene.light_pos[k] = hs.light_pos[k];
+    s.scene.light_emit[k] = hs.light_emit[k];
+    s.scene.light_normal[k] = hs.light_normal[k];
+  }
+  s.scene.light_half[0] = hs.light_half[0];
+  s.scene.light_half[1] = hs.light_half[1];
+  s.bvh_depth = std::max(bvh.depth, 1);
+  s.num_nodes = (int)bvh.nodes.size();
+  s.bvh_bytes = bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(q4);
+  s.scene_version = g_scene_version;
+}
+
+// optix_wrapper.cpp:1168-1253: convert the snapshot, build the region grid on the host, upload.
+void upload_guide(State& s) {
+  s.guide_version = g_snap_version;
+  s.guide_valid = false;
+  const uint32_t nr = (uint32_t)g_snap_regions.size(), nl = (uint32_t)g_snap_lobes.size();
+  if (nr == 0) return;
+  std::vector<GuideRegion> hreg(nr);
+  std::vector<GuideLobe> hlobe(nl);
+  static_assert(sizeof(GuideRegion) == sizeof(pgl_region) && sizeof(GuideLobe) == sizeof(pgl_lobe), "layout");
+  memcpy(hreg.data(), g_snap_regions.data(), nr * sizeof(GuideRegion));
+  if (nl) memcpy(hlobe.data(), g_snap_lobes.data(), nl * sizeof(GuideLobe));
+  float bmin[3] = {1e30f, 1e30f, 1e30f}, bmax[3] = {-1e30f, -1e30f, -1e30f};
+  for (uint32_t i = 0; i < nr; ++i)
+    for (int k = 0; k < 3; ++k) {
+      bmin[k] = std::fmin(bmin[k], hreg[i].bmin[k]);
+      bmax[k] = std::fmax(bmax[k], hreg[i].bmax[k]);
+    }
+  int res[3];
+  for (int k = 0; k < 3; ++k) res[k] = g_grid_res[k] <= 0 ? 1 : g_grid_res[k];
+  float cell[3];
+  for (int k = 0; k < 3; ++k) cell[k] = (bmax[k] - bmin[k]) / (float)res[k];
+  std::vector<uint32_t> grid((size_t)res[0] * (size_t)res[1] * (size_t)res[2], 0xFFFFFFFFu);
+  for (uint32_t r = 0; r < nr; ++r) {
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = (int)std::floor((hreg[r].bmin[k] - bmin[k]) / cell[k]);
+      hi[k] = (int)std::floor((hreg[r].bmax[k] - bmin[k]) / cell[k]);
+      lo[k] = std::max(0, std::min(res[k] - 1, lo[k]));
+      hi[k] = std::max(0, std::min(res[k] - 1, hi[k]));
+    }
+    for (int z = lo[2]; z <= hi[2]; ++z)
+      for (int y = lo[1]; y <= hi[1]; ++y)
+        for (int x = lo[0]; x <= hi[0]; ++x) {
+          const size_t idx = ((size_t)z * (size_t)res[1] + (size_t)y) * (size_t)res[0] + (size_t)x;
+          if (grid[idx] == 0xFFFFFFFFu) grid[idx] = r;  // first region wins
+        }
+  }
+  upload(s.d_regions, hreg);
+  upload(s.d_lobes, hlobe);
+  upload(s.d_grid, grid);
+  s.guide.regions = s.d_regions;
+  s.guide.lobes = s.d_lobes;
+  s.guide.grid = s.d_grid;
+  for (int k = 0; k < 3; ++k) {
+    s.guide.res[k] = res[k];
+    s.guide.gmin[k] = bmin[k];
+    s.guide.cell[k] = cell[k];
+  }
+  s.guide_valid = nl > 0;
+}
+
+// optix_wrapper.cpp:784-920
+State* make_state(int W, int H) {
+  State* s = new State();
+  s->device = device_index();
+  HIP_CHECK(hipSetDevice(s->device));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, s->device));
+  s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  s->width = W;
+  s->height = H;
+  const float eye[3] = {0.f, 3.f, 1.f}, look[3] = {0.f, 0.f, 1.f}, up[3] = {0.f, 0.f, 1.f};
+  set_camera(*s, eye, look, up, 45.f);
+  HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  upload_scene(*s);
+  const size_t px = (size_t)W * (size_t)H;
+  s->st_o = dev_alloc<q4>(px); s->st_d = dev_alloc<q4>(px); s->st_s = dev_alloc<q4>(px);
+  s->st_m = dev_alloc<u4>(px); s->acc = dev_alloc<q4>(px); s->hits = dev_alloc<q4>(px);
+  s->sh_o = dev_alloc<q4>(px); s->sh_d = dev_alloc<q4>(px); s->sh_c = dev_alloc<q4>(px);
+  s->started = dev_alloc<int>(px);
+  s->queue[0] = dev_alloc<uint32_t>(px);
+  s->queue[1] = dev_alloc<uint32_t>(px);
+  s->counters = dev_alloc<uint32_t>(CNT_WORDS);
+  s->ray_counters = dev_alloc<unsigned long long>(2);
+  HIP_CHECK(hipMemset(s->ray_counters, 0, 2 * sizeof(unsigned long long)));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), 2 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  s->d_out_rgb = dev_alloc<float>(px * 3);
+  s->d_out_bayer = dev_alloc<float>(px);
+  for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreateWithFlags(&s->ev_slot[i], hipEventDisableTiming));
+  HIP_CHECK(hipEventCreate(&s->ev_begin));
+  HIP_CHECK(hipEventCreate(&s->ev_end));
+  if (g_train_capacity > 0) {  // optix_wrapper.cpp:874-880
+    s->train_capacity = g_train_capacity;
+    s->d_train = dev_alloc<TrainRec>(g_train_capacity);
+    s->d_train_idx = dev_alloc<uint32_t>(1);
+    HIP_CHECK(hipMemset(s->d_train_idx, 0, sizeof(uint32_t)));
+  }
+  if (!g_snap_regions.empty()) upload_guide(*s);
+  return s;
+}
+
+// optix_wrapper.cpp:1087-1100
+State& ensure_handle(int w, int h) {
+  if (!g_handle || w != g_last_w || h != g_last_h) {
+    delete g_handle;
+    g_handle = make_state(w, h);
+    g_last_w = w;
+    g_last_h = h;
+    if (!g_frame_pinned) g_frame = 0;  // a fresh renderer starts at frame 0 (optix_wrapper.cpp:907)
+  }
+  State& s = *g_handle;
+  HIP_CHECK(hipSetDevice(s.device));
+  if (s.scene_version != g_scene_version) upload_scene(s);
+  if (s.guide_version != g_snap_version) upload_guide(s);
+  return s;
+}
+
+struct Timer {
+  State& s;
+  int kernel;
+  bool on;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timer(State& st, int k, bool enabled, uint64_t work) : s(st), kernel(k), on(enabled) {
+    g_kstats[k].launches++;
+    g_kstats[k].work += work;
+    if (on) {
+      HIP_CHECK(hipEventCreate(&a));
+      HIP_CHECK(hipEventCreate(&b));
+      HIP_CHECK(hipEventRecord(a, s.stream));
+    }
+  }
+  ~Timer() {
+    if (on) {
+      HIP_CHECK(hipEventRecord(b, s.stream));
+      s.timed.push_back(TimedLaunch{kernel, a, b});
+    }
+  }
+};
+
+void resolve_timers(State& s) {
+  for (TimedLaunch& t : s.timed) {
+    float ms = 0.f;
+    HIP_CHECK(hipEventSynchronize(t.stop));
+    HIP_CHECK(hipEventElapsedTime(&ms, t.start, t.stop));
+    g_kstats[t.kernel].total_ms += ms;
+    g_kstats[t.kernel].timed++;
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  s.timed.clear();
+}
+
+RenderParams make_params(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
+  RenderParams p;
+  memset(&p, 0, sizeof(p));
+  p.scene = s.scene;
+  p.guide = s.guide;
+  p.cam = s.cam;
+  p.width = s.width;
+  p.height = s.height;
+  p.frame = frame;
+  p.max_depth = std::max(1, std::min(max_depth, 255));
+  p.sample_begin = sample_begin;
+  p.sample_count = sample_count;
+  p.strict = strict ? 1 : 0;
+  p.guiding = (g_guiding_enabled && s.guide_valid) ? 1 : 0;
+  p.stack_depth = s.bvh_depth;
+  p.st_o = s.st_o; p.st_d = s.st_d; p.st_s = s.st_s; p.st_m = s.st_m; p.acc = s.acc;
+  p.started = s.started;
+  p.queue[0] = s.queue[0]; p.queue[1] = s.queue[1];
+  p.counters = s.counters;
+  p.ray_counters = s.ray_counters;
+  p.hits = s.hits;
+  p.sh_o = s.sh_o; p.sh_d = s.sh_d; p.sh_c = s.sh_c;
+  // optix_device.cu:432: training records are captured whenever the ring exists
+  p.train = s.d_train;
+  p.train_write_idx = s.d_train_idx;
+  p.train_capacity = s.train_capacity;
+  return p;
+}
+
+// The batch loop (optix_wrapper.cpp:1002-1021) re-thought for a wavefront: iterations are
+// enqueued back to back and the live-pixel count is read back once per batch of iterations,
+// one batch behind the GPU, instead of one blocking sync per 4 samples.
+void render_core(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
+  const size_t px = (size_t)s.width * (size_t)s.height;
+  RenderParams p = make_params(s, sample_begin, sample_count, max_depth, frame, strict);
+  HIP_CHECK(hipEventRecord(s.ev_begin, s.stream));
+  HIP_CHECK(hipMemsetAsync(s.st_m, 0, px * sizeof(u4), s.stream));
+  HIP_CHECK(hipMemsetAsync(s.st_s, 0, px * sizeof(q4), s.stream));
+  HIP_CHECK(hipMemsetAsync(s.acc, 0, px * sizeof(q4), s.stream));
+  HIP_CHECK(hipMemsetAsync(s.started, 0, px * sizeof(int), s.stream));
+  launch_iota(s.queue[0], (uint32_t)px, s.stream);
+  uint32_t init_counters[CNT_WORDS] = {0};
+  init_counters[CNT_Q0] = (uint32_t)px;
+  HIP_CHECK(hipMemcpyAsync(s.counters, init_counters, sizeof(init_counters), hipMemcpyHostToDevice, s.stream));
+  HIP_CHECK(hipStreamSynchronize(s.stream));  // init_counters is a stack buffer
+
+  LaunchCfg cfg;
+  cfg.threads = 256;
+  cfg.blocks = (int)std::min<size_t>((px + 255) / 256, (size_t)s.num_cus * 8);
+  cfg.blocks = std::max(cfg.blocks, 1);
+  cfg.stream = s.stream;
+  const bool fused = pipeline() == PT_PIPELINE_FUSED;
+  const int iters_per_batch = fused ? 4 : 16;
+  int qin = 0;
+  uint64_t iter = 0;
+  int slot = 0;
+  bool have_prev = false;
+  if (sample_count > 0) {
+    for (;;) {
+      for (int b = 0; b < iters_per_batch; ++b, ++iter) {
+        const bool timed = g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
+        if (fused) {
+          Timer t(s, PT_K_BOUNCE, timed, 0);
+          launch_bounce(p, qin, g_fused_bounces, cfg);
+        } else {
+          { Timer t(s, PT_K_GENERATE, timed, 0); launch_generate(p, qin, cfg); }
+          { Timer t(s, PT_K_EXTEND, timed, 0); launch_extend(p, qin ^ 1, cfg); }
+          { Timer t(s, PT_K_SHADE, timed, 0); launch_shade(p, qin ^ 1, cfg); }
+          { Timer t(s, PT_K_OCCLUDE, timed, 0); launch_occlude(p, qin, cfg); }
+        }
+        qin ^= 1;
+      }
+      HIP_CHECK(hipMemcpyAsync(s.h_counters + slot * CNT_WORDS, s.counters, CNT_WORDS * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, s.stream));
+      HIP_CHECK(hipEventRecord(s.ev_slot[slot], s.stream));
+      if (have_prev) {
+        const int prev = slot ^ 1;
+        HIP_CHECK(hipEventSynchronize(s.ev_slot[prev]));
+        const uint32_t* c = s.h_counters + prev * CNT_WORDS;
+        if (c[CNT_Q0] + c[CNT_Q1] == 0u) break;
+      }
+      have_prev = true;
+      slot ^= 1;
+    }
+  }
+  HIP_CHECK(hipEventRecord(s.ev_end, s.stream));
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, s.ev_begin, s.ev_end));
+  s.last_render_ms = ms;
+  resolve_timers(s);
+  unsigned long long rc[2];
+  HIP_CHECK(hipMemcpy(rc, s.ray_counters, sizeof(rc), hipMemcpyDeviceToHost));
+  g_rays_total[0] += rc[0];
+  g_rays_total[1] += rc[1];
+  HIP_CHECK(hipMemset(s.ray_counters, 0, sizeof(rc)));
+}
+
+int render_mean(State& s, int spp, int max_depth, float noise_threshold, int min_adaptive_samples) {
+  (void)noise_threshold;
+  (void)min_adaptive_samples;
+  g_frame++;  // optix_wrapper.cpp:983
+  render_core(s, 0, spp, max_depth, g_frame, mode() == PT_MODE_STRICT);
+  launch_finalize(s.acc, s.started, s.d_out_rgb, (uint32_t)((size_t)s.width * (size_t)s.height), 0, s.stream);
+  return 0;
+}
+
+template <typename T>
+struct DevBuf {
+  T* d = nullptr;
+  size_t n = 0;
+  explicit DevBuf(size_t count) : n(count) { d = dev_alloc<T>(count); }
+  DevBuf(const T* h, size_t count) : n(count) {
+    d = dev_alloc<T>(count);
+    if (count) HIP_CHECK(hipMemcpy(d, h, count * sizeof(T), hipMemcpyHostToDevice));
+  }
+  ~DevBuf() { dev_free(d); }
+  void download(T* h) const {
+    if (n) HIP_CHECK(hipMemcpy(h, d, n * sizeof(T), hipMemcpyDeviceToHost));
+  }
+};
+State& dbg_state() { return ensure_handle(g_last_w > 0 ? g_last_w : 16, g_last_h > 0 ? g_last_h : 16); }
+
+}  // namespace
+
+State::~State() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  for (TimedLaunch& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+  dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade);
+  dev_free(st_o); dev_free(st_d); dev_free(st_s); dev_free(st_m); dev_free(acc); dev_free(hits);
+  dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started);
+  dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
+  dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_demosaic_tmp);
+  dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid);
+  if (h_counters) (void)hipHostFree(h_counters);
+  for (int i = 0; i < 2; ++i) if (ev_slot[i]) (void)hipEventDestroy(ev_slot[i]);
+  if (ev_begin) (void)hipEventDestroy(ev_begin);
+  if (ev_end) (void)hipEventDestroy(ev_end);
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace pt
+
+using namespace pt;
+
+// ======================================================================== Part 1
+extern "C" {
+
+int optix_render_rgb(int w, int h, int spp, int max_depth, float noise_threshold, int min_adaptive_samples, float* out_rgb) {
+  State& s = ensure_handle(w, h);
+  if (!out_rgb) return -1;  // optix_wrapper.cpp:980
+  render_mean(s, spp, max_depth, noise_threshold, min_adaptive_samples);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  HIP_CHECK(hipMemcpy(out_rgb, s.d_out_rgb, (size_t)w * (size_t)h * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int optix_render_bayer_f32(int w, int h, int spp, int max_depth, float noise_threshold, int min_adaptive_samples,
+                           int pattern, float* out_raw) {
+  State& s = ensure_handle(w, h);
+  optix_ctx_set_bayer(&s, pattern);  // optix_wrapper.cpp:1113
+  if (!out_raw) return -1;
+  render_mean(s, spp, max_depth, noise_threshold, min_adaptive_samples);
+  launch_mosaic(s.d_out_rgb, s.d_out_bayer, w, h, s.bayer_pattern, 1.0f, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  HIP_CHECK(hipMemcpy(out_raw, s.d_out_bayer, (size_t)w * (size_t)h * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+void* optix_alloc_host(size_t bytes) {
+  HIP_CHECK(hipSetDevice(device_index()));
+  void* p = nullptr;
+  HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+  return p;
+}
+void optix_free_host(void* ptr) {
+  if (ptr) HIP_CHECK(hipHostFree(ptr));
+}
+void optix_synchronize(void) {
+  if (g_handle) {
+    HIP_CHECK(hipStreamSynchronize(g_handle->stream));
+    HIP_CHECK(hipStreamSynchronize(g_handle->copy_stream));
+  }
+}
+
+void* optix_ctx_create(int width, int height) { return make_state(width, height); }
+void optix_ctx_destroy(void* handle) {
+  State* s = static_cast<State*>(handle);
+  if (s == g_handle) g_handle = nullptr;
+  delete s;
+}
+void optix_ctx_set_bayer(void* handle, int pattern) { static_cast<State*>(handle)->bayer_pattern = pattern; }
+void optix_ctx_set_camera(void* handle, float ex, float ey, float ez, float lx, float ly, float lz, float ux, float uy,
+                          float uz, float vfov_deg) {
+  const float eye[3] = {ex, ey, ez}, look[3] = {lx, ly, lz}, up[3] = {ux, uy, uz};
+  set_camera(*static_cast<State*>(handle), eye, look, up, vfov_deg);
+}
+
+// ---- guiding (optix_wrapper.cpp:1168-1299)
+void guiding_upload_snapshot(const struct pgl_region* regions, uint32_t n_regions, const struct pgl_lobe* lobes,
+                             uint32_t n_lobes) {
+  g_snap_regions.assign(regions, regions + n_regions);
+  g_snap_lobes.assign(lobes, lobes + n_lobes);
+  g_snap_version++;
+  if (g_handle) {
+    HIP_CHECK(hipSetDevice(g_handle->device));
+    upload_guide(*g_handle);
+  }
+}
+void guiding_set_enabled(int enabled) { g_guiding_enabled = enabled; }
+void guiding_set_train_buffer_size(uint32_t n) { g_train_capacity = n; }
+void guiding_set_grid_res(int x, int y, int z) {
+  g_grid_res[0] = x; g_grid_res[1] = y; g_grid_res[2] = z;
+}
+void guiding_map_train_samples(const TrainSample** samples, uint32_t* count) {
+  static std::vector<TrainSample> host;
+  if (samples) *samples = nullptr;
+  if (count) *count = 0;
+  if (!g_handle) return;
+  State& st = *g_handle;
+  if (!st.d_train || !st.d_train_idx || st.train_capacity == 0) return;
+  HIP_CHECK(hipSetDevice(st.device));
+  host.resize(st.train_capacity);
+  static_assert(sizeof(TrainSample) == sizeof(TrainRec), "layout");
+  HIP_CHECK(hipMemcpy(host.data(), st.d_train, sizeof(TrainSample) * (size_t)st.train_capacity, hipMemcpyDeviceToHost));
+  uint32_t n = 0;
+  HIP_CHECK(hipMemcpy(&n, st.d_train_idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (samples) *samples = host.data();
+  if (count) *count = std::min(n, st.train_capacity);  // the ring wraps; never report more than it holds
+}
+void guiding_reset_train_write_idx(void) {
+  if (!g_handle || !g_handle->d_train_idx) return;
+  HIP_CHECK(hipSetDevice(g_handle->device));
+  HIP_CHECK(hipMemset(g_handle->d_train_idx, 0, sizeof(uint32_t)));
+}
+
+// ======================================================================== Part 2
+void pt_set_mode(int m) { g_mode = m == PT_MODE_STRICT ? PT_MODE_STRICT : PT_MODE_CONVERGE; }
+int pt_get_mode(void) { return mode(); }
+void pt_set_pipeline(int p) { g_pipeline = p == PT_PIPELINE_STAGED ? PT_PIPELINE_STAGED : PT_PIPELINE_FUSED; }
+int pt_get_pipeline(void) { return pipeline(); }
+void pt_set_device(int d) {
+  if (d != device_index()) {
+    delete g_handle;
+    g_handle = nullptr;
+  }
+  g_device = d;
+}
+void pt_set_frame(int frame) {
+  g_frame = frame;
+  g_frame_pinned = true;
+}
+int pt_get_frame(void) { return g_frame; }
+
+int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth, int frame,
+                                float* d_sum_rgb) {
+  State& s = ensure_handle(w, h);
+  if (!d_sum_rgb) return -1;
+  render_core(s, sample_begin, sample_count, max_depth, frame, false);
+  launch_finalize(s.acc, s.started, d_sum_rgb, (uint32_t)((size_t)w * (size_t)h), 1, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+int pt_mosaic_device(const float* d_rgb, int w, int h, int pattern, float divisor, float* d_raw) {
+  State& s = ensure_handle(w, h);
+  if (!d_rgb || !d_raw) return -1;
+  launch_mosaic(d_rgb, d_raw, w, h, pattern, divisor, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, int algo, float* d_out_rgb) {
+  if (!d_raw || !d_out_rgb) return -1;
+  HIP_CHECK(hipSetDevice(device_index()));
+  const size_t n = (size_t)w * (size_t)h;
+  float* tmp = dev_alloc<float>(3 * n);
+  hipStream_t st = g_handle ? g_handle->stream : nullptr;
+  hipEvent_t a, b;
+  HIP_CHECK(hipEventCreate(&a));
+  HIP_CHECK(hipEventCreate(&b));
+  HIP_CHECK(hipEventRecord(a, st));
+  launch_demosaic(d_raw, d_out_rgb, tmp, w, h, pattern, algo, st);
+  HIP_CHECK(hipEventRecord(b, st));
+  HIP_CHECK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+  g_kstats[PT_K_DEMOSAIC].total_ms += ms;
+  g_kstats[PT_K_DEMOSAIC].timed++;
+  g_kstats[PT_K_DEMOSAIC].launches++;
+  g_kstats[PT_K_DEMOSAIC].work += n;
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  dev_free(tmp);
+  return 0;
+}
+
+int pt_demosaic_f32(const float* raw, int w, int h, int pattern, int algo, float* out_rgb) {
+  if (!raw || !out_rgb) return -1;
+  HIP_CHECK(hipSetDevice(device_index()));
+  const size_t n = (size_t)w * (size_t)h;
+  float* d_raw = dev_alloc<float>(n);
+  float* d_out = dev_alloc<float>(3 * n);
+  HIP_CHECK(hipMemcpy(d_raw, raw, n * sizeof(float), hipMemcpyHostToDevice));
+  pt_demosaic_device(d_raw, w, h, pattern, algo, d_out);
+  HIP_CHECK(hipMemcpy(out_rgb, d_out, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+  dev_free(d_raw);
+  dev_free(d_out);
+  return 0;
+}
+
+void pt_get_ray_counts(uint64_t* radiance_rays, uint64_t* shadow_rays) {
+  if (radiance_rays) *radiance_rays = g_rays_total[0];
+  if (shadow_rays) *shadow_rays = g_rays_total[1];
+}
+void pt_reset_ray_counts(void) { g_rays_total[0] = g_rays_total[1] = 0; }
+void pt_set_kernel_timing(int every_nth_launch) { g_timing_every = every_nth_launch; }
+void pt_get_kernel_stats(int kernel, double* total_ms, uint64_t* timed_launches, uint64_t* launches, uint64_t* work_items) {
+  if (kernel < 0 || kernel >= PT_K_COUNT) return;
+  if (total_ms) *total_ms = g_kstats[kernel].total_ms;
+  if (timed_launches) *timed_launches = g_kstats[kernel].timed;
+  if (launches) *launches = g_kstats[kernel].launches;
+  if (work_items) *work_items = g_kstats[kernel].work;
+}
+void pt_reset_kernel_stats(void) {
+  for (KernelStat& k : g_kstats) k = KernelStat();
+}
+double pt_last_render_ms(void) { return g_handle ? g_handle->last_render_ms : 0.0; }
+
+void pt_scene_cornell(void) {
+  g_scene = make_cornell();
+  g_scene_init = true;
+  g_scene_version++;
+}
+void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv) {
+  g_scene = make_synthetic(seed, n_objects, subdiv);
+  g_scene_init = true;
+  g_scene_version++;
+}
+void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
+                        const float* materials11) {
+  g_scene = make_from_triangles(vertices, n_vertices, indices, n_triangles, materials11);
+  g_scene_init = true;
+  g_scene_version++;
+}
+void pt_scene_info(int* n_triangles, int* n_bvh_nodes, int* bvh_depth, size_t* bvh_bytes) {
+  State& s = ensure_handle(g_last_w > 0 ? g_last_w : 16, g_last_h > 0 ? g_last_h : 16);
+  if (n_triangles) *n_triangles = (int)s.scene.num_tris;
+  if (n_bvh_nodes) *n_bvh_nodes = s.num_nodes;
+  if (bvh_depth) *bvh_depth = s.bvh_depth;
+  if (bvh_bytes) *bvh_bytes = s.bvh_bytes;
+}
+void pt_scene_get(float* vertices, uint32_t* indices, float* normals, float* materials11) {
+  HostScene& hs = scene();
+  if (vertices) memcpy(vertices, hs.vertices.data(), hs.vertices.size() * sizeof(float));
+  if (indices) memcpy(indices, hs.indices.data(), hs.indices.size() * sizeof(uint32_t));
+  if (normals) memcpy(normals, hs.normals.data(), hs.normals.size() * sizeof(float));
+  if (materials11) memcpy(materials11, hs.materials.data(), hs.materials.size() * sizeof(Material));
+}
+
+// ---- stage-level entry points
+
+int pt_dbg_pcg(uint64_t seed, int n, uint32_t* out_u32, float* out_f32) {
+  State& s = dbg_state();
+  DevBuf<uint32_t> u((size_t)n);
+  DevBuf<float> f((size_t)n);
+  launch_dbg_pcg(seed, n, u.d, f.d, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  if (out_u32) u.download(out_u32);
+  if (out_f32) f.download(out_f32);
+  return 0;
+}
+int pt_dbg_blue_noise(int n, const int* xysf, float* out_uv, float* out_jitter) {
+  State& s = dbg_state();
+  DevBuf<int> in(xysf, (size_t)n * 4);
+  DevBuf<float> uv((size_t)n * 2), jit((size_t)n * 2);
+  launch_dbg_blue_noise(n, in.d, uv.d, jit.d, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  if (out_uv) uv.download(out_uv);
+  if (out_jitter) jit.download(out_jitter);
+  return 0;
+}
+int pt_dbg_camera_dirs(int w, int h, int n, const int* xy, const float* jitter, float* out_dirs) {
+  State& s = ensure_handle(w, h);
+  DevBuf<int> dxy(xy, (size_t)n * 2);
+  DevBuf<float> dj(jitter, (size_t)n * 2), dd((size_t)n * 3);
+  launch_dbg_camera(s.cam, w, h, n, dxy.d, dj.d, dd.d, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  dd.download(out_dirs);
+  return 0;
+}
+int pt_trace_rays(int n, const float* origins, const float* dirs, const float* tmin, const float* tmax, int any_hit,
+                  int* out_prim, float* out_t, float* out_b1, float* out_b2) {
+  State& s = dbg_state();
+  DevBuf<float> o(origins, (size_t)n * 3), d(dirs, (size_t)n * 3), t0(tmin, (size_t)n), t1(tmax, (size_t)n);
+  DevBuf<int> prim((size_t)n);
+  DevBuf<float> t((size_t)n), b1((size_t)n), b2((size_t)n);
+  HIP_CHECK(hipMemset(t.d, 0, (size_t)std::max(n, 1) * sizeof(float)));
+  HIP_CHECK(hipMemset(b1.d, 0, (size_t)std::max(n, 1) * sizeof(float)));
+  HIP_CHECK(hipMemset(b2.d, 0, (size_t)std::max(n, 1) * sizeof(float)));
+  launch_trace_rays(s.scene, s.bvh_depth, n, o.d, d.d, t0.d, t1.d, any_hit, prim.d, t.d, b1.d, b2.d, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  if (out_prim) prim.download(out_prim);
+  if (out_t) t.download(out_t);
+  if (out_b1) b1.download(out_b1);
+  if (out_b2) b2.download(out_b2);
+  return 0;
+}
+int pt_dbg_shade(int n, pt_path_rec* recs, const int* prim, const float* b1, const float* b2, int frame, int max_depth,
+                 int* out_shadow_traced) {
+  State& s = dbg_state();
+  static_assert(sizeof(pt_path_rec) == sizeof(DbgPathRec), "layout");
+  DevBuf<DbgPathRec> r(reinterpret_cast<const DbgPathRec*>(recs), (size_t)n);
+  DevBuf<int> p(prim, (size_t)n), sh((size_t)n);
+  DevBuf<float> db1(b1, (size_t)n), db2(b2, (size_t)n);
+  const int guiding = (g_guiding_enabled && s.guide_valid) ? 1 : 0;
+  launch_dbg_shade(s.scene, s.guide, guiding, s.bvh_depth, n, r.d, p.d, db1.d, db2.d, frame,
+                   std::max(1, std::min(max_depth, 255)), sh.d, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  r.download(reinterpret_cast<DbgPathRec*>(recs));
+  if (out_shadow_traced) sh.download(out_shadow_traced);
+  return 0;
+}
+int pt_dbg_guiding(int n, const float* positions, const float* u3, const float* wi, int* out_region, int* out_lobe,
+                   float* out_dir, float* out_pdf_dir, float* out_pdf_wi) {
+  State& s = dbg_state();
+  if (!s.guide_valid) return -1;
+  DevBuf<float> P(positions, (size_t)n * 3), U(u3, (size_t)n * 3), Wd(wi, (size_t)n * 3);
+  DevBuf<int> reg((size_t)n), lobe((size_t)n);
+  DevBuf<float> dir((size_t)n * 3), pd((size_t)n), pw((size_t)n);
+  launch_dbg_guiding(s.guide, n, P.d, U.d, Wd.d, reg.d, lobe.d, dir.d, pd.d, pw.d, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  if (out_region) reg.download(out_region);
+  if (out_lobe) lobe.download(out_lobe);
+  if (out_dir) dir.download(out_dir);
+  if (out_pdf_dir) pd.download(out_pdf_dir);
+  if (out_pdf_wi) pw.download(out_pdf_wi);
+  return 0;
+}
+
+const char* pt_version(void) { return "pt_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// renderer.h -- host runtime behind the C ABI: device state, scene upload, wavefront loop.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "bvh_build.h"
+#include "pt_kernels.h"
+#include "scene.h"
+
+namespace pt {
+
+#define HIP_CHECK(call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      fprintf(stderr, "HIP error %s (%d): %s at %s:%d\n", hipGetErrorName(e_), (int)e_,          \
+              hipGetErrorString(e_), __FILE__, __LINE__);                                        \
+      std::abort();                                                                              \
+    }                                                                                            \
+  } while (0)
+
+struct KernelStat {
+  double total_ms = 0.0;
+  uint64_t timed = 0, launches = 0, work = 0;
+};
+
+struct TimedLaunch {
+  int kernel;
+  hipEvent_t start, stop;
+};
+
+// Everything that lives on one GPU for one resolution (the reference's State,
+// optix_wrapper.cpp:221-367, minus the OptiX pipeline objects).
+struct State {
+  int device = 0;
+  int width = 0, height = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  CameraView cam{};
+  int bayer_pattern = 0;
+
+  // scene on device
+  BvhNode* d_nodes = nullptr;
+  q4* d_tris = nullptr;
+  ShadeRec* d_shade = nullptr;
+  SceneView scene{};
+  int bvh_depth = 1, num_nodes = 0;
+  size_t bvh_bytes = 0;
+  uint64_t scene_version = 0;
+
+  // path state / queues
+  q4 *st_o = nullptr, *st_d = nullptr, *st_s = nullptr, *acc = nullptr, *hits = nullptr;
+  q4 *sh_o = nullptr, *sh_d = nullptr, *sh_c = nullptr;
+  u4* st_m = nullptr;
+  int* started = nullptr;
+  uint32_t* queue[2] = {nullptr, nullptr};
+  uint32_t* counters = nullptr;
+  unsigned long long* ray_counters = nullptr;
+  uint32_t* h_counters = nullptr;  // pinned, 2 slots x CNT_WORDS
+  hipEvent_t ev_slot[2] = {nullptr, nullptr};
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+  // outputs
+  float* d_out_rgb = nullptr;
+  float* d_out_bayer = nullptr;
+  float* d_demosaic_tmp = nullptr;
+
+  // guiding
+  TrainRec* d_train = nullptr;
+  uint32_t* d_train_idx = nullptr;
+  uint32_t train_capacity = 0;
+  GuideRegion* d_regions = nullptr;
+  GuideLobe* d_lobes = nullptr;
+  uint32_t* d_grid = nullptr;
+  GuideView guide{};
+  bool guide_valid = false;
+  uint64_t guide_version = 0;
+
+  std::vector<TimedLaunch> timed;
+  double last_render_ms = 0.0;
+
+  ~State();
+};
+
+}  // namespace pt

@@ -1,0 +1,239 @@
+"""ptamd -- Python host binding of libpt_hip.so, the MI355X path-tracing backend.
+
+This is the ctypes counterpart of the reference's Rust FFI block (src/main.rs:9-32,
+src/guiding.rs:31-68): the same symbols with the same argument meaning, plus the pt_*
+additions declared in include/pt_api.h.  There is no CPU fallback: importing works
+anywhere (so that the symbol table can be inspected), but every compute call needs the
+HIP library and a GPU, and raises if the library is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(ROOT, "libpt_hip.so")
+
+MODE_STRICT, MODE_CONVERGE = 0, 1
+PIPELINE_STAGED, PIPELINE_FUSED = 0, 1
+K_GENERATE, K_EXTEND, K_SHADE, K_OCCLUDE, K_BOUNCE, K_DEMOSAIC = range(6)
+KERNEL_NAMES = ["generate", "extend", "shade", "occlude", "bounce", "demosaic"]
+
+
+class PglRegion(C.Structure):  # src/guiding.rs:13-20
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("lobe_ofs", C.c_uint32), ("lobe_num", C.c_uint32)]
+
+
+class PglLobe(C.Structure):  # src/guiding.rs:21-28
+    _fields_ = [("mu", C.c_float * 3), ("kappa", C.c_float), ("weight", C.c_float), ("rgb", C.c_float * 3)]
+
+
+class TrainSample(C.Structure):  # src/guiding.rs:5-11
+    _fields_ = [("position", C.c_float * 3), ("dir_in", C.c_float * 3), ("contrib", C.c_float * 3),
+                ("is_delta", C.c_uint32)]
+
+
+class PathRec(C.Structure):  # pt_path_rec
+    _fields_ = [("radiance", C.c_float * 3), ("throughput", C.c_float * 3), ("origin", C.c_float * 3),
+                ("direction", C.c_float * 3), ("seed", C.c_uint64), ("depth", C.c_int), ("done", C.c_int),
+                ("prev_pdf_bsdf", C.c_float), ("prev_pdf_valid", C.c_int), ("px", C.c_int), ("py", C.c_int),
+                ("sample", C.c_int), ("rng_dim", C.c_int)]
+
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes); also the list of symbols include/pt_api.h declares.
+SIGNATURES = {
+    "optix_render_rgb": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _fp]),
+    "optix_render_bayer_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _fp]),
+    "optix_alloc_host": (C.c_void_p, [C.c_size_t]),
+    "optix_free_host": (None, [C.c_void_p]),
+    "optix_synchronize": (None, []),
+    "optix_ctx_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "optix_ctx_destroy": (None, [C.c_void_p]),
+    "optix_ctx_set_bayer": (None, [C.c_void_p, C.c_int]),
+    "optix_ctx_set_camera": (None, [C.c_void_p] + [C.c_float] * 10),
+    "guiding_upload_snapshot": (None, [C.POINTER(PglRegion), C.c_uint32, C.POINTER(PglLobe), C.c_uint32]),
+    "guiding_set_enabled": (None, [C.c_int]),
+    "guiding_set_train_buffer_size": (None, [C.c_uint32]),
+    "guiding_map_train_samples": (None, [C.POINTER(C.POINTER(TrainSample)), _u32p]),
+    "guiding_reset_train_write_idx": (None, []),
+    "guiding_set_grid_res": (None, [C.c_int, C.c_int, C.c_int]),
+    "pgl_dev_create": (C.c_void_p, [C.c_int]),
+    "pgl_dev_destroy": (None, [C.c_void_p]),
+    "pgl_field_create": (C.c_void_p, [C.c_void_p, _fp, _fp]),
+    "pgl_field_destroy": (None, [C.c_void_p]),
+    "pgl_samples_create": (C.c_void_p, []),
+    "pgl_samples_destroy": (None, [C.c_void_p]),
+    "pgl_samples_add_surface": (None, [C.c_void_p, _fp, _fp, _fp, C.c_int]),
+    "pgl_field_update": (None, [C.c_void_p, C.c_void_p]),
+    "pgl_field_snapshot": (None, [C.c_void_p, C.POINTER(C.POINTER(PglRegion)), _u32p,
+                                  C.POINTER(C.POINTER(PglLobe)), _u32p]),
+    "pt_set_mode": (None, [C.c_int]),
+    "pt_get_mode": (C.c_int, []),
+    "pt_set_pipeline": (None, [C.c_int]),
+    "pt_get_pipeline": (C.c_int, []),
+    "pt_set_device": (None, [C.c_int]),
+    "pt_set_frame": (None, [C.c_int]),
+    "pt_get_frame": (C.c_int, []),
+    "pt_render_accumulate_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pt_mosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "pt_demosaic_f32": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "pt_demosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pt_write_exr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _fp, C.c_float]),
+    "pt_read_exr": (C.c_int, [C.c_char_p, _ip, _ip, _fp, C.c_size_t]),
+    "pt_get_ray_counts": (None, [_u64p, _u64p]),
+    "pt_reset_ray_counts": (None, []),
+    "pt_set_kernel_timing": (None, [C.c_int]),
+    "pt_get_kernel_stats": (None, [C.c_int, C.POINTER(C.c_double), _u64p, _u64p, _u64p]),
+    "pt_reset_kernel_stats": (None, []),
+    "pt_last_render_ms": (C.c_double, []),
+    "pt_scene_cornell": (None, []),
+    "pt_scene_synthetic": (None, [C.c_uint32, C.c_int, C.c_int]),
+    "pt_scene_triangles": (None, [_fp, C.c_int, _u32p, C.c_int, _fp]),
+    "pt_scene_info": (None, [_ip, _ip, _ip, C.POINTER(C.c_size_t)]),
+    "pt_scene_get": (None, [_fp, _u32p, _fp, _fp]),
+    "pt_dbg_pcg": (C.c_int, [C.c_uint64, C.c_int, _u32p, _fp]),
+    "pt_dbg_blue_noise": (C.c_int, [C.c_int, _ip, _fp, _fp]),
+    "pt_dbg_camera_dirs": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _fp, _fp]),
+    "pt_trace_rays": (C.c_int, [C.c_int, _fp, _fp, _fp, _fp, C.c_int, _ip, _fp, _fp, _fp]),
+    "pt_dbg_shade": (C.c_int, [C.c_int, C.POINTER(PathRec), _ip, _fp, _fp, C.c_int, C.c_int, _ip]),
+    "pt_dbg_guiding": (C.c_int, [C.c_int, _fp, _fp, _fp, _ip, _ip, _fp, _fp, _fp]),
+    "pt_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpt_hip.so (built in-tree by `make -C rust-pathtracer_amd`).  No fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C {ROOT}` (hipcc, gfx950). "
+                "There is no CPU fallback for the render path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+# ------------------------------------------------------------------ render entry points
+def render_rgb(w, h, spp, max_depth=32, noise_threshold=0.0, min_adaptive_samples=32):
+    """optix_render_rgb (src/main.rs:47-67): returns float32 [h, w, 3]."""
+    out = np.empty((h, w, 3), np.float32)
+    rc = lib().optix_render_rgb(w, h, spp, max_depth, noise_threshold, min_adaptive_samples, _f(out))
+    if rc != 0:
+        raise RuntimeError(f"optix_render_rgb returned {rc}")
+    return out
+
+
+def render_bayer(w, h, spp, max_depth=32, noise_threshold=0.0, min_adaptive_samples=32, pattern=0):
+    """optix_render_bayer_f32 (src/main.rs:81-103): returns float32 [h, w]."""
+    out = np.empty((h, w), np.float32)
+    rc = lib().optix_render_bayer_f32(w, h, spp, max_depth, noise_threshold, min_adaptive_samples, pattern, _f(out))
+    if rc != 0:
+        raise RuntimeError(f"optix_render_bayer_f32 returned {rc}")
+    return out
+
+
+def render_accumulate_device(sum_tensor, w, h, sample_begin, sample_count, max_depth, frame):
+    """Adds this chunk's per-pixel sums into a CUDA float32 tensor of w*h*3 elements."""
+    assert sum_tensor.is_cuda and sum_tensor.is_contiguous() and sum_tensor.numel() == w * h * 3
+    rc = lib().pt_render_accumulate_device(w, h, sample_begin, sample_count, max_depth, frame, sum_tensor.data_ptr())
+    if rc != 0:
+        raise RuntimeError(f"pt_render_accumulate_device returned {rc}")
+
+
+def demosaic(raw, pattern=0, algo=0):
+    raw = np.ascontiguousarray(raw, np.float32)
+    h, w = raw.shape
+    out = np.empty((h, w, 3), np.float32)
+    rc = lib().pt_demosaic_f32(_f(raw), w, h, pattern, algo, _f(out))
+    if rc != 0:
+        raise RuntimeError(f"pt_demosaic_f32 returned {rc}")
+    return out
+
+
+def write_exr(path, rgb, exposure=1.0):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w, _ = rgb.shape
+    return lib().pt_write_exr(path.encode(), w, h, _f(rgb), exposure)
+
+
+def read_exr(path):
+    w, h = C.c_int(), C.c_int()
+    rc = lib().pt_read_exr(path.encode(), C.byref(w), C.byref(h), None, 0)
+    if rc != 0:
+        raise RuntimeError(f"pt_read_exr header: {rc}")
+    out = np.empty((h.value, w.value, 3), np.float32)
+    rc = lib().pt_read_exr(path.encode(), C.byref(w), C.byref(h), _f(out), out.size)
+    if rc != 0:
+        raise RuntimeError(f"pt_read_exr: {rc}")
+    return out
+
+
+def ray_counts():
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().pt_get_ray_counts(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def kernel_stats(kernel):
+    ms, timed, launches, work = C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    lib().pt_get_kernel_stats(kernel, C.byref(ms), C.byref(timed), C.byref(launches), C.byref(work))
+    return {"total_ms": ms.value, "timed": timed.value, "launches": launches.value, "work": work.value}
+
+
+def scene_info():
+    nt, nn, dp, nb = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    lib().pt_scene_info(C.byref(nt), C.byref(nn), C.byref(dp), C.byref(nb))
+    return {"triangles": nt.value, "nodes": nn.value, "depth": dp.value, "bvh_bytes": nb.value}
+
+
+def trace_rays(origins, dirs, tmin=None, tmax=None, any_hit=False):
+    o = np.ascontiguousarray(origins, np.float32)
+    d = np.ascontiguousarray(dirs, np.float32)
+    n = o.shape[0]
+    t0 = np.zeros(n, np.float32) if tmin is None else np.ascontiguousarray(tmin, np.float32)
+    t1 = np.full(n, 1e16, np.float32) if tmax is None else np.ascontiguousarray(tmax, np.float32)
+    prim = np.zeros(n, np.int32)
+    t = np.zeros(n, np.float32)
+    b1 = np.zeros(n, np.float32)
+    b2 = np.zeros(n, np.float32)
+    lib().pt_trace_rays(n, _f(o), _f(d), _f(t0), _f(t1), 1 if any_hit else 0, _i(prim), _f(t), _f(b1), _f(b2))
+    return prim, t, b1, b2
+
+
+def upload_snapshot(regions, lobes):
+    """regions: (n,8) [bmin3,bmax3,ofs,num]; lobes: (m,8) [mu3,kappa,weight,rgb3]."""
+    n, m = len(regions), len(lobes)
+    R = (PglRegion * max(n, 1))()
+    for i, r in enumerate(regions):
+        R[i].bmin[:] = [float(x) for x in r[0:3]]
+        R[i].bmax[:] = [float(x) for x in r[3:6]]
+        R[i].lobe_ofs = int(r[6])
+        R[i].lobe_num = int(r[7])
+    Lb = (PglLobe * max(m, 1))()
+    for i, l in enumerate(lobes):
+        Lb[i].mu[:] = [float(x) for x in l[0:3]]
+        Lb[i].kappa = float(l[3])
+        Lb[i].weight = float(l[4])
+        Lb[i].rgb[:] = [float(x) for x in l[5:8]]
+    lib().guiding_upload_snapshot(R, n, Lb, m)

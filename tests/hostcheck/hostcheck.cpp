@@ -1,0 +1,206 @@
+// hostcheck.cpp -- TEST HARNESS: compiles the integrator's device headers (pt_bvh.h,
+// pt_shade.h, ...) and the host BVH builder with a plain C++ compiler so that the device
+// LOGIC can be exercised against the oracle on machines without a GPU (and under gdb /
+// host sanitizers).  It is never part of libpt_hip.so and nothing in the product links it.
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <atomic>
+
+#include "../../rust-pathtracer_amd/csrc/bvh_build.h"
+#include "../../rust-pathtracer_amd/csrc/pt_bvh.h"
+#include "../../rust-pathtracer_amd/csrc/pt_shade.h"
+#include "../../rust-pathtracer_amd/csrc/scene.h"
+
+using namespace pt;
+
+namespace {
+HostScene g_hs;
+BvhBuildResult g_bvh;
+std::vector<ShadeRec> g_recs;
+SceneView g_sv;
+CameraView g_cam;
+std::vector<GuideRegion> g_regions;
+std::vector<GuideLobe> g_lobes;
+std::vector<uint32_t> g_grid;
+GuideView g_gv;
+int g_guiding = 0;
+bool g_ready = false;
+
+void finish_scene() {
+  const int nt = g_hs.num_tris();
+  g_bvh = build_bvh8(g_hs.vertices.data(), g_hs.indices.data(), nt);
+  g_recs.assign((size_t)(nt > 0 ? nt : 1), ShadeRec{});
+  for (int i = 0; i < nt; ++i) {
+    ShadeRec& r = g_recs[(size_t)i];
+    const Material& m = g_hs.materials[(size_t)i];
+    for (int k = 0; k < 3; ++k) {
+      r.v0[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + 0] + k];
+      r.v1[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + 1] + k];
+      r.v2[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + 2] + k];
+      r.base[k] = m.base[k];
+      r.emission[k] = m.emission[k];
+    }
+    const float* n = &g_hs.normals[3 * (size_t)i];
+    float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (len < 1e-20f) len = 1e-20f;
+    for (int k = 0; k < 3; ++k) r.ng[k] = n[k] * (1.0f / len);
+    r.roughness = m.roughness; r.ior = m.ior; r.transmission = m.transmission;
+  }
+  g_sv.nodes = g_bvh.nodes.data();
+  g_sv.tris = g_bvh.tris.data();
+  g_sv.shade = g_recs.data();
+  g_sv.num_tris = (uint32_t)nt;
+  for (int k = 0; k < 3; ++k) {
+    g_sv.light_pos[k] = g_hs.light_pos[k]; g_sv.light_emit[k] = g_hs.light_emit[k]; g_sv.light_normal[k] = g_hs.light_normal[k];
+  }
+  g_sv.light_half[0] = g_hs.light_half[0]; g_sv.light_half[1] = g_hs.light_half[1];
+  g_ready = true;
+}
+void ensure() {
+  if (!g_ready) { g_hs = make_cornell(); finish_scene(); }
+}
+void set_camera(int w, int h) {
+  // same arithmetic as renderer.cpp set_camera() with the default arguments
+  const float eye[3] = {0.f, 3.f, 1.f}, look[3] = {0.f, 0.f, 1.f}, up[3] = {0.f, 0.f, 1.f};
+  float W[3] = {look[0] - eye[0], look[1] - eye[1], look[2] - eye[2]};
+  auto norm = [](float v[3]) { float l = sqrtf(v[0]*v[0]+v[1]*v[1]+v[2]*v[2]); float inv = 1.0f / l; v[0]*=inv; v[1]*=inv; v[2]*=inv; };
+  norm(W);
+  float U[3] = {W[1]*up[2]-W[2]*up[1], W[2]*up[0]-W[0]*up[2], W[0]*up[1]-W[1]*up[0]};
+  norm(U);
+  float V[3] = {U[1]*W[2]-U[2]*W[1], U[2]*W[0]-U[0]*W[2], U[0]*W[1]-U[1]*W[0]};
+  const float th = tanf(45.0f * float(M_PI) / 180.0f * 0.5f), aspect = float(w) / float(h);
+  for (int k = 0; k < 3; ++k) { g_cam.eye[k] = eye[k]; g_cam.w[k] = W[k]; g_cam.u[k] = th * aspect * U[k]; g_cam.v[k] = th * V[k]; }
+}
+}  // namespace
+
+extern "C" {
+
+void hc_scene_cornell() { g_hs = make_cornell(); finish_scene(); }
+void hc_scene_synthetic(uint32_t seed, int n, int subdiv) { g_hs = make_synthetic(seed, n, subdiv); finish_scene(); }
+void hc_scene_triangles(const float* v, int nv, const uint32_t* idx, int nt, const float* m11) {
+  g_hs = make_from_triangles(v, nv, idx, nt, m11); finish_scene();
+}
+void hc_scene_info(int* ntris, int* nnodes, int* depth) {
+  ensure();
+  *ntris = g_hs.num_tris(); *nnodes = (int)g_bvh.nodes.size(); *depth = g_bvh.depth;
+}
+void hc_scene_get(float* v, uint32_t* idx, float* nrm, float* m11) {
+  ensure();
+  if (v) memcpy(v, g_hs.vertices.data(), g_hs.vertices.size() * 4);
+  if (idx) memcpy(idx, g_hs.indices.data(), g_hs.indices.size() * 4);
+  if (nrm) memcpy(nrm, g_hs.normals.data(), g_hs.normals.size() * 4);
+  if (m11) memcpy(m11, g_hs.materials.data(), g_hs.materials.size() * sizeof(Material));
+}
+int hc_num_vertices() { ensure(); return (int)(g_hs.vertices.size() / 3); }
+
+void hc_trace_rays(int n, const float* o, const float* d, const float* tmin, const float* tmax, int any_hit,
+                   int* prim, float* t, float* b1, float* b2) {
+  ensure();
+  for (int i = 0; i < n; ++i) {
+    LocalStack st;
+    Hit h = trace_ray(g_sv, mk3(o[3*i], o[3*i+1], o[3*i+2]), mk3(d[3*i], d[3*i+1], d[3*i+2]), tmin[i], tmax[i],
+                      any_hit != 0, st, 64);
+    if (any_hit) { prim[i] = h.prim >= 0 ? 1 : 0; }
+    else { prim[i] = h.prim; t[i] = h.t; b1[i] = h.b1; b2[i] = h.b2; }
+  }
+}
+
+void hc_guide_set(const float* regions8, int nr, const float* lobes8, int nl, const uint32_t* grid, const int* res,
+                  const float* gmin, const float* cell, int enabled) {
+  g_regions.resize((size_t)nr); g_lobes.resize((size_t)nl);
+  memcpy(g_regions.data(), regions8, (size_t)nr * 32);
+  memcpy(g_lobes.data(), lobes8, (size_t)nl * 32);
+  g_grid.assign(grid, grid + (size_t)res[0] * res[1] * res[2]);
+  g_gv.regions = g_regions.data(); g_gv.lobes = g_lobes.data(); g_gv.grid = g_grid.data();
+  for (int k = 0; k < 3; ++k) { g_gv.res[k] = res[k]; g_gv.gmin[k] = gmin[k]; g_gv.cell[k] = cell[k]; }
+  g_guiding = enabled;
+}
+
+struct HcRec {
+  float radiance[3], throughput[3], origin[3], direction[3];
+  unsigned long long seed; int depth, done; float prev_pdf_bsdf; int prev_pdf_valid; int px, py, sample, rng_dim;
+};
+void hc_shade(int n, HcRec* recs, const int* prim, const float* b1, const float* b2, int frame, int max_depth, int* shadow) {
+  ensure();
+  for (int i = 0; i < n; ++i) {
+    HcRec& r = recs[i];
+    PathState ps;
+    ps.o = mk3(r.origin[0], r.origin[1], r.origin[2]);
+    ps.d = mk3(r.direction[0], r.direction[1], r.direction[2]);
+    ps.T = mk3(r.throughput[0], r.throughput[1], r.throughput[2]);
+    ps.sum = mk3(0.f); ps.seed = r.seed; ps.prev_pdf = r.prev_pdf_bsdf;
+    const uint32_t dim = r.rng_dim < 2 ? (uint32_t)r.rng_dim : 2u;
+    ps.flags = ((uint32_t)r.depth & kDepthMask) | (dim << kDimShift) | (r.prev_pdf_valid ? kPrevValid : 0u) | kAlive;
+    RandCtx rc{r.px, r.py, r.sample, frame};
+    Hit h{prim[i], 0.f, b1[i], b2[i]};
+    ShadowRay sr;
+    ShadeParams sp{frame, max_depth, g_guiding};
+    shade_hit(g_sv, g_gv, sp, rc, ps, h, sr, nullptr, nullptr);
+    if (sr.valid) {
+      LocalStack st;
+      Hit o = trace_ray(g_sv, sr.o, sr.d, 0.0f, sr.tmax, true, st, 64);
+      if (o.prim < 0) ps.sum += sr.contrib;
+    }
+    shadow[i] = sr.valid ? 1 : 0;
+    r.radiance[0] = ps.sum.x; r.radiance[1] = ps.sum.y; r.radiance[2] = ps.sum.z;
+    r.throughput[0] = ps.T.x; r.throughput[1] = ps.T.y; r.throughput[2] = ps.T.z;
+    r.origin[0] = ps.o.x; r.origin[1] = ps.o.y; r.origin[2] = ps.o.z;
+    r.direction[0] = ps.d.x; r.direction[1] = ps.d.y; r.direction[2] = ps.d.z;
+    r.seed = ps.seed; r.depth = (int)ps_depth(ps); r.done = (ps.flags & kAlive) ? 0 : 1;
+    r.prev_pdf_bsdf = ps.prev_pdf; r.prev_pdf_valid = (ps.flags & kPrevValid) ? 1 : 0; r.rng_dim = (int)ps_dim(ps);
+  }
+}
+
+// The per-pixel sample loop of the wavefront kernels, run sequentially per pixel.
+void hc_render(int w, int h, int sample_begin, int sample_count, int max_depth, int frame, int strict, int nthreads,
+               float* out_sum_rgb, unsigned long long* rays) {
+  ensure();
+  set_camera(w, h);
+  std::atomic<int> next_row{0};
+  std::atomic<unsigned long long> r0{0}, r1{0};
+  auto work = [&]() {
+    unsigned long long a = 0, b = 0;
+    for (;;) {
+      int y = next_row.fetch_add(1);
+      if (y >= h) break;
+      for (int x = 0; x < w; ++x) {
+        const uint32_t pixel = (uint32_t)(y * w + x);
+        float acc[3] = {0, 0, 0};
+        uint64_t seed = 0;
+        for (int local = 0; local < sample_count; ++local) {
+          const int s = strict ? (local & 3) : sample_begin + local;
+          uint64_t start = strict ? ((local & 3) == 0 ? pixel_seed(frame, pixel) : seed)
+                                  : (local == 0 ? chunk_seed(frame, pixel, sample_begin) : seed);
+          PathState ps;
+          generate_path(g_cam, x, y, s, frame, w, h, start, ps);
+          RandCtx rc{x, y, s, frame};
+          ShadeParams sp{frame, max_depth, g_guiding};
+          while (ps.flags & kAlive) {
+            LocalStack st;
+            Hit hit = trace_ray(g_sv, ps.o, ps.d, 0.0f, 1e16f, false, st, 64);
+            a++;
+            ShadowRay sr;
+            shade_hit(g_sv, g_gv, sp, rc, ps, hit, sr, nullptr, nullptr);
+            if (sr.valid) {
+              b++;
+              Hit o = trace_ray(g_sv, sr.o, sr.d, 0.0f, sr.tmax, true, st, 64);
+              if (o.prim < 0) ps.sum += sr.contrib;
+            }
+          }
+          seed = ps.seed;
+          acc[0] += ps.sum.x; acc[1] += ps.sum.y; acc[2] += ps.sum.z;
+        }
+        for (int k = 0; k < 3; ++k) out_sum_rgb[3 * (size_t)pixel + k] = acc[k];
+      }
+    }
+    r0 += a; r1 += b;
+  };
+  std::vector<std::thread> th;
+  for (int i = 0; i < (nthreads > 1 ? nthreads : 1); ++i) th.emplace_back(work);
+  for (auto& t : th) t.join();
+  if (rays) { rays[0] = r0; rays[1] = r1; }
+}
+
+}  // extern "C"
