@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (and spp/s) of the default scene at 1920x1080, 1024 spp, depth 32.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one full render pass of the hot path: every pixel of the 1080p frame takes 1024
+samples through the wavefront integrator (BVH traversal + shading + NEE), sums stay in HBM.
+With N ranks each GPU renders its own 1024-sample chunk of the same frame (weak scaling: the
+image gets N*1024 spp) and the per-pixel sums are all-reduced over RCCL at the end of the step.
+A ray is one BVH query: every radiance ray plus every shadow ray actually traced.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "rust-pathtracer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# Algorithmic work per ray used for the roofline figures (fixed by construction of the
+# wavefront records: 68 B path state read + written, 16 B hit record, 44 B shadow record and
+# queue indices per path segment of one radiance + at most one shadow ray = 332 B / 2 rays).
+BYTES_PER_RAY = 166.0
+FLOP_PER_RAY = 600.0
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK_TFLOPS = 157.3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--max-depth", type=int, default=32)
+    ap.add_argument("--pipeline", choices=["fused", "staged"], default="fused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(args.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import ptamd
+    from ptamd import sharded
+    L = ptamd.lib()
+    L.pt_set_device(local_rank)
+    L.pt_set_mode(ptamd.MODE_CONVERGE)
+    L.pt_set_pipeline(ptamd.PIPELINE_FUSED if args.pipeline == "fused" else ptamd.PIPELINE_STAGED)
+    w, h, spp = args.width, args.height, args.spp
+    sums = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+    begin, count = sharded.chunk_of(rank, spp)
+
+    def step(frame):
+        sums.zero_()
+        torch.cuda.synchronize(dev)
+        ptamd.render_accumulate_device(sums, w, h, begin, count, args.max_depth, frame)
+        if world > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(1 + i)
+    L.pt_reset_ray_counts()
+    L.pt_reset_kernel_stats()
+    L.pt_set_kernel_timing(1)  # HIP events on the render stream around every wavefront launch
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(101 + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.pt_set_kernel_timing(0)
+
+    rr, rs = ptamd.ray_counts()
+    stats = torch.tensor([elapsed, float(rr), float(rs)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:3].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, rr_all, rs_all = float(tmax[0]), float(tot[0]), float(tot[1])
+    else:
+        rr_all, rs_all = float(rr), float(rs)
+    rays_all = rr_all + rs_all
+
+    if rank == 0:
+        kid = ptamd.K_BOUNCE if args.pipeline == "fused" else ptamd.K_EXTEND
+        kst = ptamd.kernel_stats(kid)
+        avg_ms = kst["total_ms"] / max(kst["timed"], 1)
+        # dominant kernel: rays this rank traced per launch of it (the staged extend kernel only traces radiance rays)
+        rays_per_launch = ((rr + rs) if args.pipeline == "fused" else rr) / max(kst["launches"], 1)
+        achieved_gbs = BYTES_PER_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved_tflops = FLOP_PER_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.pipeline, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mrays/s at 1080p default scene (radiance + shadow rays)",
+            "value": rays_all / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (built-in Cornell scene of the reference, generated in-process)",
+            "config": {"workload": f"cornell_{w}x{h}_{spp}spp_depth{args.max_depth}_converge", "pipeline": args.pipeline,
+                       "spp_per_gpu": spp, "total_spp": spp * world, "parallelism": f"sample-sharded x{world}"},
+            "spp_per_s": spp * world * args.steps / elapsed,
+            "paths_per_s": float(w) * h * spp * world * args.steps / elapsed,
+            "rays_per_path": rays_all / (float(w) * h * spp * world * args.steps),
+            "roofline": {"bound": "hbm", "kernel": ptamd.KERNEL_NAMES[kid], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": kst["launches"], "rays_per_launch": rays_per_launch,
+                         "bytes_per_ray": BYTES_PER_RAY},
+            "roofline_valu": {"bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved_tflops / VALU_PEAK_TFLOPS, "flop_per_ray": FLOP_PER_RAY},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import orc
+            cores = min(os.cpu_count() or 1, 16)
+            t = time.perf_counter()
+            _, _, _, crays = orc.render(w, h, args.cpu_spp, max_depth=args.max_depth, frame=101, mode=orc.CONVERGE, nthreads=cores)
+            ct = time.perf_counter() - t
+            result["cpu_baseline"] = {"value": sum(crays) / ct / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                      "sample": f"same scene and camera, {w}x{h}, {args.cpu_spp} spp ({sum(crays)} rays, {ct:.1f} s); "
+                                                "rays/s does not depend on spp"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

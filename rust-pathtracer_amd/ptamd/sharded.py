@@ -1,0 +1,53 @@
+"""Sample-sharded rendering across the GPUs of one node: one process per GPU, per-GPU sums
+reduced over RCCL (torch.distributed backend "nccl"), as a collective only at the end.
+
+The reference is single-GPU (optix_wrapper.cpp:788 takes device 0 and nothing else); what is
+sharded here is the sample loop of optix_wrapper.cpp:1002-1021.  Samples are independent, so
+rank r renders the global sample indices [r*spp, (r+1)*spp) of every pixel and the ranks'
+per-pixel sums add up to the sums of one GPU rendering the same chunks one after another.
+"""
+import torch
+import torch.distributed as dist
+
+
+def chunk_of(rank, spp_per_rank):
+    """Global sample range [begin, begin+count) rendered by `rank` (weak scaling)."""
+    return rank * spp_per_rank, spp_per_rank
+
+
+def split_samples(total_spp, world):
+    """Strong scaling: contiguous ranges covering [0,total_spp), sizes differing by at most 1."""
+    base, rem = divmod(total_spp, world)
+    out, begin = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((begin, n))
+        begin += n
+    return out
+
+
+def render_sharded(render_chunk, w, h, begin, count, total_spp, group=None):
+    """render_chunk(sum_tensor, begin, count) adds this rank's per-pixel RGB sums into
+    sum_tensor (float32, w*h*3, on the rank's device).  Returns the mean image [h,w,3] on
+    every rank (all-reduce), identical on all ranks."""
+    device = render_chunk.device if hasattr(render_chunk, "device") else None
+    sums = torch.zeros(w * h * 3, dtype=torch.float32, device=device)
+    render_chunk(sums, begin, count)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return (sums / float(total_spp)).view(h, w, 3)
+
+
+class DeviceChunkRenderer:
+    """render_chunk callable backed by pt_render_accumulate_device on this rank's GPU."""
+
+    def __init__(self, w, h, max_depth, frame, device):
+        import ptamd
+        self.pt = ptamd
+        self.w, self.h, self.max_depth, self.frame = w, h, max_depth, frame
+        self.device = torch.device(device)
+        ptamd.lib().pt_set_device(self.device.index or 0)
+
+    def __call__(self, sums, begin, count):
+        torch.cuda.synchronize(self.device)  # sums was zeroed on torch's stream
+        self.pt.render_accumulate_device(sums, self.w, self.h, begin, count, self.max_depth, self.frame)

@@ -1,0 +1,387 @@
+"""CPU tests of everything around the kernels: the C-ABI surface, the host BVH builder, the
+device headers compiled for the host (tests/hostcheck) against the oracle, EXR I/O, the
+stand-in guiding trainer, and the multi-process reduce path (gloo, world_size 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def P(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ------------------------------------------------------------------ C-ABI surface
+def test_library_exports_every_declared_symbol(pt):
+    """Every PT_EXPORT declaration in include/pt_api.h resolves in libpt_hip.so and is bound."""
+    hdr = open(os.path.join(ROOT, "include", "pt_api.h")).read()
+    declared = set(re.findall(r"PT_EXPORT\s+[\w\s\*]+?\b(\w+)\s*\(", hdr))
+    assert len(declared) >= 50
+    L = pt.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared but not exported"
+    assert declared == set(pt.SIGNATURES), declared ^ set(pt.SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pt.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert declared <= exported
+    # the reference's exported names (src/main.rs:9-32, src/guiding.rs:31-68) are all there
+    for name in ["optix_render_rgb", "optix_render_bayer_f32", "optix_alloc_host", "optix_free_host",
+                 "optix_synchronize", "pgl_dev_create", "pgl_field_snapshot", "guiding_upload_snapshot",
+                 "guiding_map_train_samples", "guiding_set_grid_res"]:
+        assert name in exported
+
+
+def test_product_has_no_oracle_or_cpu_fallback(pt):
+    """The shipped library and package never reference the oracle."""
+    out = subprocess.check_output(["nm", "-D", pt.LIB_PATH], text=True)
+    assert "orc_" not in out and "hc_" not in out
+    for dirpath, _, files in os.walk(pt.ROOT):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "liborc" not in src and "pt_oracle" not in src and "hostcheck" not in src or f == "pt_types.h", f
+
+
+def test_struct_layouts_match_reference_sizes(pt):
+    # SURVEY of the reference: pgl_region 32 B, pgl_lobe 32 B, TrainSample 40 B (src/guiding.rs:5-28)
+    assert C.sizeof(pt.PglRegion) == 32 and C.sizeof(pt.PglLobe) == 32 and C.sizeof(pt.TrainSample) == 40
+
+
+# ------------------------------------------------------------------ BVH builder + traversal logic
+def _scene_arrays(hc):
+    nt, nn, dp = C.c_int(), C.c_int(), C.c_int()
+    hc.hc_scene_info(C.byref(nt), C.byref(nn), C.byref(dp))
+    nv = hc.hc_num_vertices()
+    V = np.zeros((nv, 3), np.float32)
+    I = np.zeros((nt.value, 3), np.uint32)
+    N = np.zeros((nt.value, 3), np.float32)
+    M = np.zeros((nt.value, 11), np.float32)
+    hc.hc_scene_get(P(V), P(I, C.c_uint32), P(N), P(M))
+    return V, I, N, M, nn.value, dp.value
+
+
+def test_builtin_scene_equals_oracle_scene(hostcheck, oracle):
+    hostcheck.hc_scene_cornell()
+    V, I, N, M, nodes, depth = _scene_arrays(hostcheck)
+    L = oracle.lib()
+    assert np.array_equal(V, np.ctypeslib.as_array(L.orc_scene_vertices(), shape=(48, 3)))
+    assert np.array_equal(I, np.ctypeslib.as_array(L.orc_scene_indices(), shape=(24, 3)))
+    assert np.array_equal(N, np.ctypeslib.as_array(L.orc_scene_normals(), shape=(24, 3)))
+    OM = L.orc_scene_materials()
+    for i in range(24):
+        want = list(OM[i].base) + [OM[i].metallic, OM[i].roughness, OM[i].ior, OM[i].alpha, OM[i].transmission] + list(OM[i].emission)
+        assert M[i].tolist() == pytest.approx(want, abs=0)
+    assert depth <= 3 and nodes <= 8
+
+
+def _random_rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.99, 0.99, (n, 3)).astype(np.float32)
+    o[:, 2] = rng.uniform(0.01, 1.99, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+def _hc_trace(hc, o, d, tmax=None, any_hit=0):
+    n = len(o)
+    tmin = np.zeros(n, np.float32)
+    tmax = np.full(n, 1e16, np.float32) if tmax is None else tmax
+    prim = np.zeros(n, np.int32)
+    t, b1, b2 = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    hc.hc_trace_rays(n, P(o), P(d), P(tmin), P(tmax), any_hit, P(prim, C.c_int), P(t), P(b1), P(b2))
+    return prim, t, b1, b2
+
+
+def _orc_trace(oracle, o, d):
+    L = oracle.lib()
+    fp = C.POINTER(C.c_float)
+    prim = np.zeros(len(o), np.int32)
+    t = np.zeros(len(o), np.float32)
+    for i in range(len(o)):
+        h = L.orc_trace_closest(o[i].ctypes.data_as(fp), d[i].ctypes.data_as(fp), 0.0, 1e16)
+        prim[i], t[i] = h.prim, h.t
+    return prim, t
+
+
+def test_traversal_logic_matches_brute_force_cornell(hostcheck, oracle):
+    hostcheck.hc_scene_cornell()
+    o, d = _random_rays(20000, 1)
+    prim, t, b1, b2 = _hc_trace(hostcheck, o, d)
+    op, ot = _orc_trace(oracle, o, d)
+    assert (prim != op).sum() == 0
+    hit = op >= 0
+    assert np.abs(t[hit] - ot[hit]).max() < 1e-5
+    assert ((b1 >= 0) & (b2 >= 0) & (b1 + b2 <= 1.0 + 1e-5))[hit].all()
+
+
+def test_traversal_logic_matches_brute_force_soup(hostcheck, oracle):
+    """A deeper tree: 64 spheres x 320 triangles + the room; rays checked against the oracle's
+    brute-force loop over the same triangles."""
+    hostcheck.hc_scene_synthetic(7, 64, 2)
+    try:
+        V, I, N, M, nodes, depth = _scene_arrays(hostcheck)
+        assert len(I) == 12 + 64 * 320 and depth >= 4
+        oracle.lib().orc_scene_set(P(V), len(V), P(I, C.c_uint32), len(I), None)
+        o, d = _random_rays(3000, 2)
+        prim, t, _, _ = _hc_trace(hostcheck, o, d)
+        op, ot = _orc_trace(oracle, o, d)
+        assert (prim != op).sum() == 0
+        assert np.abs(t - ot)[op >= 0].max() < 1e-5
+        tmax = np.random.default_rng(3).uniform(0.05, 2.0, len(o)).astype(np.float32)
+        occ, _, _, _ = _hc_trace(hostcheck, o, d, tmax, any_hit=1)
+        L = oracle.lib()
+        fp = C.POINTER(C.c_float)
+        want = np.array([L.orc_trace_any(o[i].ctypes.data_as(fp), d[i].ctypes.data_as(fp), 0.0, float(tmax[i]))
+                         for i in range(len(o))])
+        assert np.array_equal(occ, want)
+    finally:
+        oracle.lib().orc_scene_set(None, 0, None, 0, None)
+        hostcheck.hc_scene_cornell()
+
+
+def test_watertight_no_leak_through_shared_edges(hostcheck):
+    """Rays aimed exactly at quad diagonals, edges and corners of the closed part of the box
+    must hit something (the two triangles of a quad share their diagonal)."""
+    hostcheck.hc_scene_cornell()
+    o = np.tile(np.array([[0.123, 0.456, 1.0]], np.float32), (0, 1))
+    targets = []
+    for s in np.linspace(-1, 1, 41):
+        targets += [(s, s * 1.0, 0.0), (s, -1.0, 1.0 + s), (-1.0, s, 1.0 + s), (1.0, s, 1.0 - s),
+                    (s, -1.0, 0.0), (-1.0, -1.0, 1.0 + s), (1.0, -1.0, 1.0 + s), (s, s, 2.0)]
+    targets = np.array(targets, np.float32)
+    org = np.tile(np.array([[0.123, 0.3, 1.1]], np.float32), (len(targets), 1))
+    d = targets - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    prim, t, _, _ = _hc_trace(hostcheck, org, d.astype(np.float32))
+    assert (prim >= 0).all()
+
+
+def test_empty_and_tiny_scenes(hostcheck):
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    idx = np.array([[0, 1, 2]], np.uint32)
+    hostcheck.hc_scene_triangles(P(tri), 3, P(idx, C.c_uint32), 1, None)
+    try:
+        o = np.array([[0.2, 0.2, 1.0], [2.0, 2.0, 1.0], [0.2, 0.2, -1.0]], np.float32)
+        d = np.array([[0, 0, -1], [0, 0, -1], [0, 0, 1]], np.float32)
+        prim, t, b1, b2 = _hc_trace(hostcheck, o, d)
+        assert prim.tolist() == [0, -1, 0]  # two-sided
+        assert t[0] == pytest.approx(1.0) and b1[0] == pytest.approx(0.2) and b2[0] == pytest.approx(0.2)
+        hostcheck.hc_scene_triangles(P(tri), 3, P(idx, C.c_uint32), 0, None)
+        prim, _, _, _ = _hc_trace(hostcheck, o, d)
+        assert (prim == -1).all()
+    finally:
+        hostcheck.hc_scene_cornell()
+
+
+# ------------------------------------------------------------------ shading logic vs oracle
+class HcRec(C.Structure):
+    _fields_ = [("radiance", C.c_float * 3), ("throughput", C.c_float * 3), ("origin", C.c_float * 3),
+                ("direction", C.c_float * 3), ("seed", C.c_uint64), ("depth", C.c_int), ("done", C.c_int),
+                ("prev_pdf_bsdf", C.c_float), ("prev_pdf_valid", C.c_int), ("px", C.c_int), ("py", C.c_int),
+                ("sample", C.c_int), ("rng_dim", C.c_int)]
+
+
+def make_shade_cases(oracle, n, seed, max_depth=32):
+    """Random path states arriving at random primitives of the built-in scene."""
+    L = oracle.lib()
+    rng = np.random.default_rng(seed)
+    V = np.ctypeslib.as_array(L.orc_scene_vertices(), shape=(48, 3))
+    I = np.ctypeslib.as_array(L.orc_scene_indices(), shape=(24, 3))
+    cases = []
+    for _ in range(n):
+        prim = int(rng.integers(0, 24))
+        b1, b2 = rng.uniform(0.02, 0.45, 2)
+        Pt = V[I[prim, 0]] * (1 - b1 - b2) + V[I[prim, 1]] * b1 + V[I[prim, 2]] * b2
+        org = rng.uniform(-0.9, 0.9, 3)
+        org[2] = rng.uniform(0.1, 1.9)
+        d = Pt - org
+        d /= np.linalg.norm(d)
+        r = oracle.PRD()
+        r.throughput[:] = rng.uniform(0.1, 1.0, 3).tolist()
+        r.origin[:] = org.tolist()
+        r.direction[:] = d.tolist()
+        r.seed = int(rng.integers(0, 2 ** 63))
+        r.depth = int(rng.choice([0, 1, 5, max_depth - 3, max_depth - 2, max_depth - 1]))
+        r.prev_pdf_bsdf = float(rng.uniform(0.05, 3.0))
+        r.prev_pdf_valid = int(rng.integers(0, 2))
+        r.px, r.py, r.sample = int(rng.integers(0, 1920)), int(rng.integers(0, 1080)), int(rng.integers(0, 1024))
+        r.rng_dim = int(rng.choice([0, 1, 2, 7]))
+        cases.append((r, prim, float(np.float32(b1)), float(np.float32(b2))))
+    return cases
+
+
+def check_shade_against_oracle(oracle, cases, shade_fn, frame=1, max_depth=32, guide=None, rtol=2e-3):
+    """shade_fn(recs, prims, b1, b2) -> (recs_out, shadow flags).  Returns the fraction of cases
+    that agree with the oracle's closest-hit."""
+    L = oracle.lib()
+    n = len(cases)
+    recs = (HcRec * n)()
+    prims = np.zeros(n, np.int32)
+    b1 = np.zeros(n, np.float32)
+    b2 = np.zeros(n, np.float32)
+    for i, (r, p, u, v) in enumerate(cases):
+        C.memmove(C.byref(recs[i]), C.byref(r), C.sizeof(HcRec))
+        prims[i], b1[i], b2[i] = p, u, v
+    out, shadow = shade_fn(recs, prims, b1, b2)
+    agree = 0
+    for i, (r0, p, u, v) in enumerate(cases):
+        a = oracle.PRD.from_buffer_copy(r0)
+        a.radiance[:] = [0, 0, 0]
+        h = oracle.Hit(p, 0.0, u, v)
+        sh = C.c_uint64(0)
+        L.orc_closesthit(C.byref(a), C.byref(h), frame, max_depth, C.byref(guide) if guide is not None else None, C.byref(sh))
+        g = out[i]
+        ca = np.array(list(a.radiance)) * np.array(list(a.throughput))
+        cg = np.array(list(g.radiance))
+        ok = (a.seed == g.seed and a.done == g.done and a.depth == g.depth and int(sh.value) == int(shadow[i])
+              and a.prev_pdf_valid == g.prev_pdf_valid
+              and np.allclose(ca, cg, rtol=rtol, atol=1e-5)
+              and np.allclose(list(a.throughput), list(g.throughput), rtol=rtol, atol=1e-6)
+              and (a.done or (np.allclose(list(a.direction), list(g.direction), atol=2e-4)
+                              and np.allclose(list(a.origin), list(g.origin), atol=1e-5)))
+              and abs(a.prev_pdf_bsdf - g.prev_pdf_bsdf) <= rtol * abs(a.prev_pdf_bsdf) + 1e-6)
+        agree += bool(ok)
+    return agree / n
+
+
+def test_shading_logic_matches_oracle(hostcheck, oracle):
+    hostcheck.hc_scene_cornell()
+    cases = make_shade_cases(oracle, 4000, 21)
+
+    def shade(recs, prims, b1, b2):
+        shadow = np.zeros(len(prims), np.int32)
+        hostcheck.hc_shade(len(prims), recs, P(prims, C.c_int), P(b1), P(b2), 1, 32, P(shadow, C.c_int))
+        return recs, shadow
+
+    frac = check_shade_against_oracle(oracle, cases, shade)
+    assert frac > 0.995, frac
+
+
+def test_render_logic_strict_matches_oracle(hostcheck, oracle):
+    """Same seeds, same paths: the per-pixel sample loop of the kernels reproduces the oracle's
+    4-sample launch except where a grazing hit flips (a path leaving the glass box through its
+    bottom face starts at z ~ 0 and may or may not see the floor)."""
+    hostcheck.hc_scene_cornell()
+    w, h = 48, 36
+    out = np.zeros((h, w, 3), np.float32)
+    rays = (C.c_ulonglong * 2)()
+    hostcheck.hc_render(w, h, 0, 4, 32, 1, 1, 4, P(out), rays)
+    ref, _, _, orays = oracle.render(w, h, 4, frame=1, mode=oracle.STRICT)
+    close = (np.abs(out / 4 - ref) <= 1e-3 + 1e-3 * np.abs(ref)).all(axis=2).mean()
+    assert close > 0.93, close
+    assert abs(rays[0] - orays[0]) / orays[0] < 0.01 and abs(rays[1] - orays[1]) / orays[1] < 0.01
+
+
+# ------------------------------------------------------------------ EXR, trainer stand-in
+def test_exr_round_trip(pt, tmp_path):
+    rng = np.random.default_rng(0)
+    for (h, w) in [(1, 1), (3, 5), (48, 64)]:
+        img = rng.uniform(0, 20, (h, w, 3)).astype(np.float32)
+        path = str(tmp_path / f"t_{w}x{h}.exr")
+        assert pt.write_exr(path, img, 1.0) == 0
+        back = pt.read_exr(path)
+        assert np.array_equal(back, img)
+        assert pt.write_exr(path, img, 0.5) == 0  # src/main.rs:427-434: value * exposure
+        assert np.array_equal(pt.read_exr(path), img * np.float32(0.5))
+    raw = open(path, "rb").read()
+    assert raw[:4] == bytes([0x76, 0x2f, 0x31, 0x01])  # OpenEXR magic
+    for attr in (b"channels", b"compression", b"dataWindow", b"displayWindow", b"lineOrder", b"pixelAspectRatio",
+                 b"screenWindowCenter", b"screenWindowWidth"):
+        assert attr in raw[:512]
+    assert pt.lib().pt_write_exr(b"/nonexistent_dir/x.exr", 1, 1, P(np.zeros(3, np.float32)), 1.0) == -1
+
+
+def test_pgl_stand_in_trainer(pt):
+    """ABI and ownership of the pgl_* calls (openpgl_bridge.h:7-33); the trainer itself is not OpenPGL."""
+    L = pt.lib()
+    dev = L.pgl_dev_create(0)
+    lo, hi = (C.c_float * 3)(-1, -1, 0), (C.c_float * 3)(1, 1, 2)
+    field = L.pgl_field_create(dev, lo, hi)
+    samples = L.pgl_samples_create()
+    rng = np.random.default_rng(4)
+    mu = np.array([0.0, 0.0, 1.0])
+    for _ in range(5000):
+        pos = rng.uniform([-1, -1, 0], [1, 1, 2])
+        d = mu + 0.15 * rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        L.pgl_samples_add_surface(samples, (C.c_float * 3)(*pos), (C.c_float * 3)(*d), (C.c_float * 3)(0.5, 0.6, 0.7), 0)
+    L.pgl_field_update(field, samples)
+    regs, lobes = C.POINTER(pt.PglRegion)(), C.POINTER(pt.PglLobe)()
+    nr, nl = C.c_uint32(), C.c_uint32()
+    L.pgl_field_snapshot(field, C.byref(regs), C.byref(nr), C.byref(lobes), C.byref(nl))
+    assert nr.value == 64 and nl.value >= 64
+    total = 0
+    for i in range(nr.value):
+        r = regs[i]
+        assert r.lobe_ofs == total
+        total += r.lobe_num
+        ws = [lobes[r.lobe_ofs + j].weight for j in range(r.lobe_num)]
+        assert abs(sum(ws) - 1.0) < 1e-4
+        best = max(range(r.lobe_num), key=lambda j: ws[j])
+        lb = lobes[r.lobe_ofs + best]
+        assert lb.mu[2] > 0.9 and lb.kappa > 5.0
+    assert total == nl.value
+    L.pgl_samples_destroy(samples)
+    L.pgl_field_destroy(field)
+    L.pgl_dev_destroy(dev)
+
+
+# ------------------------------------------------------------------ multi-process reduce (gloo)
+_WORKER = r'''
+import os, sys, ctypes as C
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from ptamd import sharded
+hc = C.CDLL(sys.argv[3])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[4], rank=int(sys.argv[5]), world_size=2)
+rank = dist.get_rank()
+w, h, spp = 24, 16, 8
+def render_chunk(sums, begin, count):
+    out = np.zeros(w * h * 3, np.float32)
+    hc.hc_render(w, h, begin, count, 32, 1, 0, 1, out.ctypes.data_as(C.POINTER(C.c_float)), None)
+    sums += torch.from_numpy(out)
+begin, count = sharded.chunk_of(rank, spp)
+img = sharded.render_sharded(render_chunk, w, h, begin, count, 2 * spp)
+if rank == 0:
+    np.save(sys.argv[6], img.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sample_sharded_reduce_two_ranks(hostcheck, tmp_path):
+    """Two gloo ranks each render one chunk (device logic run on the host) and all-reduce the
+    sums; the result equals one process rendering both chunks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    out = str(tmp_path / "img.npy")
+    so = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+    pkg = os.path.join(ROOT, "rust-pathtracer_amd")
+    procs = [subprocess.Popen([sys.executable, str(script), pkg, HERE, so, str(port), str(r), out]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    img = np.load(out)
+    w, h, spp = 24, 16, 8
+    want = np.zeros((h, w, 3), np.float32)
+    for begin in (0, spp):
+        o = np.zeros((h, w, 3), np.float32)
+        hostcheck.hc_render(w, h, begin, spp, 32, 1, 0, 1, P(o), None)
+        want += o
+    want /= 2 * spp
+    assert np.allclose(img, want, rtol=1e-6, atol=1e-7)
+    from ptamd import sharded
+    assert sharded.split_samples(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert sharded.chunk_of(3, 512) == (1536, 512)
