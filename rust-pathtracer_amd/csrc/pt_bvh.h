@@ -70,12 +70,19 @@ PT_HD void edge_functions(float Ax, float Ay, float Bx, float By, float Cx, floa
   }
 }
 
+// Sheared coordinate of a vertex: one multiply and two explicit FMAs in a fixed order.  Left to
+// the compiler, a*b + c*d + e*f may be fused differently at different call sites (either
+// product of the first sum can be the rounded one), and a vertex shared by two triangles would
+// then get two slightly different images -- which is all it takes to open a crack along the
+// shared edge.
+PT_HD float shear_dot(f3 a, f3 r) { return __builtin_fmaf(a.z, r.z, __builtin_fmaf(a.y, r.y, a.x * r.x)); }
+
 // Returns true and updates hit when the triangle is hit inside (tmin, hit.t).
 PT_HD bool intersect_triangle(const RayShear& rs, f3 o, f3 v0, f3 v1, f3 v2, float tmin, int prim, Hit& hit) {
   const f3 A = v0 - o, B = v1 - o, C = v2 - o;
-  const float Ax = dot(A, rs.rx), Ay = dot(A, rs.ry);
-  const float Bx = dot(B, rs.rx), By = dot(B, rs.ry);
-  const float Cx = dot(C, rs.rx), Cy = dot(C, rs.ry);
+  const float Ax = shear_dot(A, rs.rx), Ay = shear_dot(A, rs.ry);
+  const float Bx = shear_dot(B, rs.rx), By = shear_dot(B, rs.ry);
+  const float Cx = shear_dot(C, rs.rx), Cy = shear_dot(C, rs.ry);
   float U, V, W;
   edge_functions(Ax, Ay, Bx, By, Cx, Cy, U, V, W);
   if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
