@@ -52,7 +52,8 @@ void launch_extend(const RenderParams& p, int q, const LaunchCfg& c);
 void launch_shade(const RenderParams& p, int q, const LaunchCfg& c);
 void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c);
 // Fused: up to `bounces` bounces per path in registers, regenerating finished samples in place.
-void launch_bounce(const RenderParams& p, int qin, int bounces, const LaunchCfg& c);
+// compact: append survivors to queue qin^1 (the caller swaps), else process queue qin in place.
+void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c);
 
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);
 // out[3p+k] (+)= acc[p].k / divisor(p); mode 0: write mean (divide by started[p]); 1: add raw sums

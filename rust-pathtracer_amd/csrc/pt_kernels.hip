@@ -89,8 +89,18 @@ __device__ __forceinline__ ShadeParams shade_params(const RenderParams& p) {
   return ShadeParams{p.frame, p.max_depth, p.guiding};
 }
 
-__device__ __forceinline__ void append_train(const RenderParams& p, bool want, const TrainRec& rec) {
+__device__ __forceinline__ TrainRec train_rec(const TrainVertex& tv) {
+  TrainRec r;
+  r.position[0] = tv.P.x; r.position[1] = tv.P.y; r.position[2] = tv.P.z;
+  r.dir_in[0] = tv.dir_in.x; r.dir_in[1] = tv.dir_in.y; r.dir_in[2] = tv.dir_in.z;
+  r.contrib[0] = tv.T_in.x; r.contrib[1] = tv.T_in.y; r.contrib[2] = tv.T_in.z;
+  r.is_delta = 0u;
+  return r;
+}
+// One atomic per wave for all lanes that captured a training vertex (optix_device.cu:438-440).
+__device__ __forceinline__ void append_train(const RenderParams& p, const TrainVertex& tv) {
   if (!p.train) return;
+  const bool want = tv.valid;
   const unsigned long long mask = __ballot(want);
   if (!mask) return;
   const uint32_t lane = threadIdx.x & 63u;
@@ -100,7 +110,7 @@ __device__ __forceinline__ void append_train(const RenderParams& p, bool want, c
   if (want) {
     uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     if (p.train_capacity) idx %= p.train_capacity;
-    p.train[idx] = rec;
+    p.train[idx] = train_rec(tv);
   }
 }
 
@@ -121,7 +131,7 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
       keep = true;
       if (!(m.w & kAlive)) {
         int local = p.started[pixel];
-        if (local > 0) {  // a sample just ended: fold it into the pixel's sum
+        if (m.w & kFoldPending) {  // a sample just ended: fold it into the pixel's sum
           const q4 s = p.st_s[pixel];
           q4 a = p.acc[pixel];
           a.x += s.x; a.y += s.y; a.z += s.z;
@@ -160,6 +170,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
 }
 
 // ---------------------------------------------------------------------------- shade
+template <bool GUIDED, bool TRAIN>
 __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
   const uint32_t n = p.counters[q];
   const uint32_t* queue = p.queue[q];
@@ -169,8 +180,8 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
     const bool valid = i < n;
     ShadowRay sr;
     sr.valid = false;
-    TrainRec tr;
-    bool want_train = false;
+    TrainVertex tv;
+    tv.valid = false;
     uint32_t pixel = 0;
     if (valid) {
       pixel = queue[i];
@@ -182,10 +193,10 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       rc.py = (int)(pixel / (uint32_t)p.width);
       rc.frame = p.frame;
       rc.s = ps_dim(ps) < 2u ? hash_sample_index(p, p.started[pixel] - 1) : 0;
-      shade_hit(p.scene, p.guide, sp, rc, ps, h, sr, p.train ? &tr : nullptr, &want_train);
+      shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
       store_state(p, pixel, ps);
     }
-    append_train(p, want_train, tr);
+    if (TRAIN) append_train(p, tv);
     const uint32_t slot = wave_append_slot(sr.valid, &p.counters[CNT_SHADOW]);
     if (sr.valid) {
       p.sh_o[slot] = q4{sr.o.x, sr.o.y, sr.o.z, sr.tmax};
@@ -217,13 +228,21 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int qnext_out) 
 }
 
 // ---------------------------------------------------------------------------- fused
-__global__ void __launch_bounds__(256) k_bounce(RenderParams p, int qin, int bounces) {
+// compact != 0: survivors are appended to the other queue (and the host swaps queues);
+// compact == 0: the queue is processed in place -- finished pixels stay in it and cost one
+// state read per launch -- and the other queue's counter is cleared for the next compaction.
+template <bool GUIDED, bool TRAIN>
+#ifndef PT_BOUNCE_WAVES
+#define PT_BOUNCE_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p, int qin, int bounces, int compact) {
   const uint32_t n = p.counters[qin];
   const uint32_t* q_in = p.queue[qin];
   uint32_t* q_out = p.queue[qin ^ 1];
   LdsStack st = lds_stack();
   const ShadeParams sp = shade_params(p);
   uint32_t rays_rad = 0, rays_sh = 0;
+  if (!compact && blockIdx.x == 0 && threadIdx.x == 0) p.counters[qin ^ 1] = 0u;
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < n;
@@ -233,45 +252,51 @@ __global__ void __launch_bounds__(256) k_bounce(RenderParams p, int qin, int bou
       pixel = q_in[i];
       PathState ps = load_state(p, pixel);
       int local = p.started[pixel];
-      q4 acc = p.acc[pixel];
-      RandCtx rc;
-      rc.px = (int)(pixel % (uint32_t)p.width);
-      rc.py = (int)(pixel / (uint32_t)p.width);
-      rc.frame = p.frame;
-      keep = true;
-      for (int b = 0; b < bounces; ++b) {
-        if (!(ps.flags & kAlive)) {
-          if (local > 0) { acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z; ps.sum = mk3(0.f); }
-          if (local >= p.sample_count) { keep = false; break; }
-          generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, local), p.frame, p.width, p.height,
-                        start_seed(p, pixel, local, ps.seed), ps);
-          local++;
+      keep = (ps.flags & (kAlive | kFoldPending)) || local < p.sample_count;
+      if (keep) {
+        RandCtx rc;
+        rc.px = (int)(pixel % (uint32_t)p.width);
+        rc.py = (int)(pixel / (uint32_t)p.width);
+        rc.frame = p.frame;
+        for (int b = 0; b < bounces; ++b) {
+          if (!(ps.flags & kAlive)) {
+            if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the pixel's sum
+              q4 acc = p.acc[pixel];
+              acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z;
+              p.acc[pixel] = acc;
+              ps.flags &= ~kFoldPending;
+            }
+            if (local >= p.sample_count) { keep = false; break; }
+            generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, local), p.frame, p.width, p.height,
+                          start_seed(p, pixel, local, ps.seed), ps);
+            local++;
+          }
+          rc.s = hash_sample_index(p, local - 1);
+          const Hit h = trace_ray(p.scene, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth);
+          rays_rad++;
+          ShadowRay sr;
+          TrainVertex tv;
+          shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
+          if (TRAIN && tv.valid && p.train) {
+            uint32_t idx = atomicAdd(p.train_write_idx, 1u);
+            if (p.train_capacity) idx %= p.train_capacity;
+            p.train[idx] = train_rec(tv);
+          }
+          if (sr.valid) {
+            rays_sh++;
+            const Hit o = trace_ray(p.scene, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth);
+            if (o.prim < 0) ps.sum += sr.contrib;
+          }
         }
-        rc.s = hash_sample_index(p, local - 1);
-        const Hit h = trace_ray(p.scene, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth);
-        rays_rad++;
-        ShadowRay sr;
-        TrainRec tr;
-        bool want_train = false;
-        shade_hit(p.scene, p.guide, sp, rc, ps, h, sr, p.train ? &tr : nullptr, &want_train);
-        if (p.train && want_train) {
-          uint32_t idx = atomicAdd(p.train_write_idx, 1u);
-          if (p.train_capacity) idx %= p.train_capacity;
-          p.train[idx] = tr;
-        }
-        if (sr.valid) {
-          rays_sh++;
-          const Hit o = trace_ray(p.scene, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth);
-          if (o.prim < 0) ps.sum += sr.contrib;
-        }
+        // a path that ended on the last bounce of this launch is folded by the next launch
+        store_state(p, pixel, ps);
+        p.started[pixel] = local;
       }
-      // a path that ended on the last bounce of this launch is folded by the next launch
-      store_state(p, pixel, ps);
-      p.started[pixel] = local;
-      p.acc[pixel] = acc;
     }
-    const uint32_t slot = wave_append_slot(keep, &p.counters[qin ^ 1]);
-    if (keep) q_out[slot] = pixel;
+    if (compact) {
+      const uint32_t slot = wave_append_slot(keep, &p.counters[qin ^ 1]);
+      if (keep) q_out[slot] = pixel;
+    }
   }
   // ray counters: wave reduction, one 64-bit atomic pair per wave
   for (int off = 32; off > 0; off >>= 1) {
@@ -283,8 +308,6 @@ __global__ void __launch_bounds__(256) k_bounce(RenderParams p, int qin, int bou
     if (rays_sh) atomicAdd(&p.ray_counters[1], (unsigned long long)rays_sh);
   }
 }
-// Resets the counter of the queue the NEXT fused launch appends to.
-__global__ void k_reset_counter(uint32_t* counters, int idx) { counters[idx] = 0u; }
 
 // ------------------------------------------------------------------------ utilities
 __global__ void k_iota(uint32_t* dst, uint32_t n) {
@@ -325,17 +348,21 @@ void launch_extend(const RenderParams& p, int q, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_shade(const RenderParams& p, int q, const LaunchCfg& c) {
-  k_shade<<<c.blocks, c.threads, 0, c.stream>>>(p, q);
+  if (p.guiding || p.train)
+    k_shade<true, true><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
+  else
+    k_shade<false, false><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
   PT_KCHECK();
 }
 void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c) {
   k_occlude<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qnext_out);
   PT_KCHECK();
 }
-void launch_bounce(const RenderParams& p, int qin, int bounces, const LaunchCfg& c) {
-  k_bounce<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qin, bounces);
-  PT_KCHECK();
-  k_reset_counter<<<1, 1, 0, c.stream>>>(p.counters, qin);  // qin is the next launch's output queue
+void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
+  if (p.guiding || p.train)
+    k_bounce<true, true><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qin, bounces, compact);
+  else
+    k_bounce<false, false><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qin, bounces, compact);
   PT_KCHECK();
 }
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {
@@ -408,7 +435,8 @@ __global__ void __launch_bounds__(256) k_dbg_shade(SceneView sc, GuideView gv, i
     const Hit h{prim[i], 0.f, b1[i], b2[i]};
     ShadowRay sr;
     const ShadeParams sp{frame, max_depth, guiding};
-    shade_hit(sc, gv, sp, rc, ps, h, sr, nullptr, nullptr);
+    TrainVertex tv;
+    shade_hit<true, false>(sc, gv, sp, rc, ps, h, sr, tv);
     if (sr.valid) {
       const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, stack_depth);
       if (o.prim < 0) ps.sum += sr.contrib;

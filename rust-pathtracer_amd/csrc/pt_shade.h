@@ -24,6 +24,7 @@ constexpr uint32_t kDepthMask = 0xffu;
 constexpr uint32_t kDimShift = 8u, kDimMask = 3u << 8;
 constexpr uint32_t kPrevValid = 1u << 10;
 constexpr uint32_t kAlive = 1u << 11;
+constexpr uint32_t kFoldPending = 1u << 12;  // the sample's sum has not been added to the pixel yet
 
 PT_HD uint32_t ps_depth(const PathState& p) { return p.flags & kDepthMask; }
 PT_HD uint32_t ps_dim(const PathState& p) { return (p.flags & kDimMask) >> kDimShift; }
@@ -106,13 +107,21 @@ PT_HD bool depth_and_roulette(PathState& ps, const RandCtx& rc, int max_depth) {
   return true;
 }
 
+// What a shading step reports for the guiding trainer (optix_device.cu:431-441): a record is
+// captured at every non-delta vertex, with the throughput the path arrived with.
+struct TrainVertex {
+  bool valid;
+  f3 P, dir_in, T_in;
+};
+
 // One bounce.  hit.prim < 0 is the radiance miss (optix_device.cu:370-375).
-// train, when non-null, receives the guiding training record of this vertex and
-// *want_train is set (the caller appends it to the ring, optix_device.cu:431-441).
+// GUIDED compiles the guided diffuse branch in (used when a field snapshot is active);
+// TRAIN fills `tv` for the caller to append to the training ring.
+template <bool GUIDED, bool TRAIN>
 PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams& sp, const RandCtx& rc,
-                     PathState& ps, const Hit& hit, ShadowRay& sr, TrainRec* train, bool* want_train) {
+                     PathState& ps, const Hit& hit, ShadowRay& sr, TrainVertex& tv) {
   sr.valid = false;
-  if (want_train) *want_train = false;
+  if (TRAIN) tv.valid = false;
   if (hit.prim < 0) {
     ps.flags &= ~kAlive;  // radiance = 0, done = 1: nothing to add
     return;
@@ -129,12 +138,11 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
   const f3 dir = ps.d;
 
   const bool is_delta = (Transmission > 0.0f) || (Roughness <= 0.0f);
-  if (!is_delta && train) {
-    train->position[0] = P.x; train->position[1] = P.y; train->position[2] = P.z;
-    train->dir_in[0] = -dir.x; train->dir_in[1] = -dir.y; train->dir_in[2] = -dir.z;
-    train->contrib[0] = ps.T.x; train->contrib[1] = ps.T.y; train->contrib[2] = ps.T.z;
-    train->is_delta = 0u;
-    *want_train = true;
+  if (TRAIN && !is_delta) {
+    tv.valid = true;
+    tv.P = P;
+    tv.dir_in = -dir;
+    tv.T_in = ps.T;
   }
 
   f3 radiance;
@@ -265,7 +273,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
       const GuideLobe* lobes = nullptr;
       uint32_t lobe_num = 0;
       bool have_guiding = false;
-      if (sp.guiding) {
+      if (GUIDED && sp.guiding) {
         const int region_id = guiding_region_id(gv, P);
         if (region_id >= 0) {
           const GuideRegion R = gv.regions[region_id];
@@ -340,7 +348,7 @@ PT_HD void generate_path(const CameraView& cam, int x, int y, int s, int frame, 
   ps.sum = mk3(0.0f);
   ps.seed = seed;
   ps.prev_pdf = 0.0f;
-  ps.flags = kAlive;
+  ps.flags = kAlive | kFoldPending;
 }
 
 }  // namespace pt

@@ -353,11 +353,13 @@ void render_core(State& s, int sample_begin, int sample_count, int max_depth, in
 
   LaunchCfg cfg;
   cfg.threads = 256;
-  cfg.blocks = (int)std::min<size_t>((px + 255) / 256, (size_t)s.num_cus * 8);
+  static const int blocks_per_cu = getenv("PT_BLOCKS_PER_CU") ? atoi(getenv("PT_BLOCKS_PER_CU")) : 8;
+  static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
+  cfg.blocks = (int)std::min<size_t>((px + 255) / 256, (size_t)s.num_cus * (size_t)std::max(blocks_per_cu, 1));
   cfg.blocks = std::max(cfg.blocks, 1);
   cfg.stream = s.stream;
   const bool fused = pipeline() == PT_PIPELINE_FUSED;
-  const int iters_per_batch = fused ? 4 : 16;
+  const int iters_per_batch = fused ? 8 : 16;
   int qin = 0;
   uint64_t iter = 0;
   int slot = 0;
@@ -367,8 +369,12 @@ void render_core(State& s, int sample_begin, int sample_count, int max_depth, in
       for (int b = 0; b < iters_per_batch; ++b, ++iter) {
         const bool timed = g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
         if (fused) {
+          // compact the pixel queue on the last launch of a batch only: finished pixels are rare
+          const int compact = (b == iters_per_batch - 1) ? 1 : 0;
           Timer t(s, PT_K_BOUNCE, timed, 0);
-          launch_bounce(p, qin, g_fused_bounces, cfg);
+          launch_bounce(p, qin, std::max(fused_bounces, 1), compact, cfg);
+          if (compact) qin ^= 1;
+          continue;
         } else {
           { Timer t(s, PT_K_GENERATE, timed, 0); launch_generate(p, qin, cfg); }
           { Timer t(s, PT_K_EXTEND, timed, 0); launch_extend(p, qin ^ 1, cfg); }

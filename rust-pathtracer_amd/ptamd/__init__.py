@@ -13,7 +13,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(ROOT, "libpt_hip.so")
+LIB_PATH = os.environ.get("PT_LIB_PATH", os.path.join(ROOT, "libpt_hip.so"))  # override: A/B builds of the same ABI
 
 MODE_STRICT, MODE_CONVERGE = 0, 1
 PIPELINE_STAGED, PIPELINE_FUSED = 0, 1

@@ -137,7 +137,8 @@ void hc_shade(int n, HcRec* recs, const int* prim, const float* b1, const float*
     Hit h{prim[i], 0.f, b1[i], b2[i]};
     ShadowRay sr;
     ShadeParams sp{frame, max_depth, g_guiding};
-    shade_hit(g_sv, g_gv, sp, rc, ps, h, sr, nullptr, nullptr);
+    TrainVertex tv;
+    shade_hit<true, false>(g_sv, g_gv, sp, rc, ps, h, sr, tv);
     if (sr.valid) {
       LocalStack st;
       Hit o = trace_ray(g_sv, sr.o, sr.d, 0.0f, sr.tmax, true, st, 64);
@@ -182,7 +183,8 @@ void hc_render(int w, int h, int sample_begin, int sample_count, int max_depth, 
             Hit hit = trace_ray(g_sv, ps.o, ps.d, 0.0f, 1e16f, false, st, 64);
             a++;
             ShadowRay sr;
-            shade_hit(g_sv, g_gv, sp, rc, ps, hit, sr, nullptr, nullptr);
+            TrainVertex tv;
+            shade_hit<true, false>(g_sv, g_gv, sp, rc, ps, hit, sr, tv);
             if (sr.valid) {
               b++;
               Hit o = trace_ray(g_sv, sr.o, sr.d, 0.0f, sr.tmax, true, st, 64);
