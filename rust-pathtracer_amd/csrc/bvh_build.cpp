@@ -45,6 +45,57 @@ struct Builder {
   std::vector<float> centroid;  // 3 per triangle
   std::vector<uint32_t> order;  // triangle permutation
   std::vector<Node2> nodes2;
+  // Optimal 2-ary -> 8-ary collapse (Ylitie, Karras, Laine 2017, section 3.1): cost[n][i] is
+  // the SAH cost of representing the subtree of n by a forest of at most i+1 slot entries.
+  struct Collapse {
+    float cost[8];
+    uint8_t split[8];  // for i >= 1: slots given to the left child, 0 = same as i-1
+    bool internal;     // i == 0: n becomes an internal 8-wide node (else a leaf entry)
+  };
+  std::vector<Collapse> dp;
+
+  void compute_collapse(int n) {
+    const float c_node = 1.0f, c_prim = 0.3f;
+    Node2& nd = nodes2[n];
+    Collapse& c = dp[(size_t)n];
+    const float area = nd.box.half_area();
+    if (nd.count > 0) {
+      for (int i = 0; i < 8; ++i) { c.cost[i] = area * c_prim * (float)nd.count; c.split[i] = 0; }
+      c.internal = false;
+      return;
+    }
+    compute_collapse(nd.left);
+    compute_collapse(nd.right);
+    const Collapse& l = dp[(size_t)nd.left];
+    const Collapse& r = dp[(size_t)nd.right];
+    float dist[8];  // dist[i]: best cost of spreading the two children over i+1 slots (i >= 1)
+    uint8_t dsplit[8];
+    for (int i = 1; i < 8; ++i) {
+      dist[i] = FLT_MAX;
+      dsplit[i] = 1;
+      for (int k = 1; k <= i; ++k) {  // k slots left, i+1-k right
+        const float v = l.cost[k - 1] + r.cost[i - k];
+        if (v < dist[i]) { dist[i] = v; dsplit[i] = (uint8_t)k; }
+      }
+    }
+    c.cost[0] = area * c_node + dist[7];
+    c.internal = true;
+    c.split[0] = 0;
+    for (int i = 1; i < 8; ++i) {
+      if (dist[i] < c.cost[i - 1]) { c.cost[i] = dist[i]; c.split[i] = dsplit[i]; }
+      else { c.cost[i] = c.cost[i - 1]; c.split[i] = 0; }
+    }
+  }
+  // roots of the forest that represents subtree n in at most i+1 slots
+  void forest(int n, int i, int* out, int& count) const {
+    const Node2& nd = nodes2[n];
+    if (nd.count > 0) { out[count++] = n; return; }
+    while (i > 0 && dp[(size_t)n].split[i] == 0) --i;
+    if (i == 0) { out[count++] = n; return; }
+    const int k = dp[(size_t)n].split[i];
+    forest(nd.left, k - 1, out, count);
+    forest(nd.right, i - k, out, count);
+  }
 
   int build2(int first, int count) {
     Node2 n;
@@ -149,29 +200,25 @@ struct Emitter {
 
   // returns the number of internal-node levels below and including this node
   int emit(uint32_t out_index, int n2) {
-    // gather up to 8 children by repeatedly opening the largest internal child
+    // children of this node: the cost-optimal forest of up to 8 entries below n2
     int child[8];
     int nchild = 0;
     const Node2& root = b.nodes2[n2];
     if (root.count > 0) {
       child[nchild++] = n2;
     } else {
-      child[nchild++] = root.left;
-      child[nchild++] = root.right;
-      while (nchild < 8) {
-        int best = -1;
-        float best_area = -1.f;
-        for (int i = 0; i < nchild; ++i) {
-          const Node2& c = b.nodes2[child[i]];
-          if (c.count > 0) continue;
-          const float a = c.box.half_area();
-          if (a > best_area) { best_area = a; best = i; }
+      int k = 1;
+      {  // the split that compute_collapse() chose for "n2 as an internal node"
+        const auto& l = b.dp[(size_t)root.left];
+        const auto& r = b.dp[(size_t)root.right];
+        float best = FLT_MAX;
+        for (int kk = 1; kk <= 7; ++kk) {
+          const float v = l.cost[kk - 1] + r.cost[7 - kk];
+          if (v < best) { best = v; k = kk; }
         }
-        if (best < 0) break;
-        const Node2& c = b.nodes2[child[best]];
-        child[best] = c.left;
-        child[nchild++] = c.right;
       }
+      b.forest(root.left, k - 1, child, nchild);
+      b.forest(root.right, 7 - k, child, nchild);
     }
     // node box and grid
     Box nb;
@@ -312,6 +359,8 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   }
   b.nodes2.reserve(2 * (size_t)num_tris);
   const int root2 = b.build2(0, num_tris);
+  b.dp.resize(b.nodes2.size());
+  b.compute_collapse(root2);
   out.tris.resize(3 * (size_t)num_tris);
   out.nodes.reserve((size_t)num_tris / 2 + 16);
   out.nodes.resize(1);

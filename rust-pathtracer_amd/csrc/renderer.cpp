@@ -36,7 +36,7 @@ uint64_t g_scene_version = 1;
 int g_timing_every = 0;
 KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
-int g_fused_bounces = 8;
+int g_fused_bounces = 16;
 
 int env_choice(const char* name, const char* a, const char* b, int dflt) {
   const char* v = getenv(name);
@@ -353,7 +353,7 @@ void render_core(State& s, int sample_begin, int sample_count, int max_depth, in
 
   LaunchCfg cfg;
   cfg.threads = 256;
-  static const int blocks_per_cu = getenv("PT_BLOCKS_PER_CU") ? atoi(getenv("PT_BLOCKS_PER_CU")) : 8;
+  static const int blocks_per_cu = getenv("PT_BLOCKS_PER_CU") ? atoi(getenv("PT_BLOCKS_PER_CU")) : 16;
   static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
   cfg.blocks = (int)std::min<size_t>((px + 255) / 256, (size_t)s.num_cus * (size_t)std::max(blocks_per_cu, 1));
   cfg.blocks = std::max(cfg.blocks, 1);
