@@ -20,6 +20,8 @@ struct RenderParams {
   int strict;                      // 1: replay the reference's 4-sample launches literally
   int guiding;
   int stack_depth;                 // traversal stack entries per lane
+  uint32_t scene_nodes;            // number of BVH nodes
+  int scene_in_lds;                // stage a small scene in LDS (fused kernel)
   // per-pixel path state, SoA of 16-byte words
   q4* st_o;   // origin.xyz, throughput.x
   q4* st_d;   // direction.xyz, throughput.y

@@ -231,15 +231,32 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int qnext_out) 
 // compact != 0: survivors are appended to the other queue (and the host swaps queues);
 // compact == 0: the queue is processed in place -- finished pixels stay in it and cost one
 // state read per launch -- and the other queue's counter is cleared for the next compaction.
-template <bool GUIDED, bool TRAIN>
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 3
 #endif
+template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
 __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p, int qin, int bounces, int compact) {
   const uint32_t n = p.counters[qin];
   const uint32_t* q_in = p.queue[qin];
   uint32_t* q_out = p.queue[qin ^ 1];
   LdsStack st = lds_stack();
+  SceneView sc = p.scene;
+  if (LDS_SCENE) {
+    // Small scenes: stage nodes, triangles and shading records in LDS behind the traversal
+    // stacks, so the divergent 16-byte gathers of traversal and shading never leave the CU.
+    u4* dst = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
+    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_tris * 3u, n_shade16 = p.scene.num_tris * 6u;
+    const u4* src_n = reinterpret_cast<const u4*>(p.scene.nodes);
+    const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
+    const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
+    for (uint32_t k = threadIdx.x; k < n_nodes16; k += blockDim.x) dst[k] = src_n[k];
+    for (uint32_t k = threadIdx.x; k < n_tris16; k += blockDim.x) dst[n_nodes16 + k] = src_t[k];
+    for (uint32_t k = threadIdx.x; k < n_shade16; k += blockDim.x) dst[n_nodes16 + n_tris16 + k] = src_s[k];
+    __syncthreads();
+    sc.nodes = reinterpret_cast<const BvhNode*>(dst);
+    sc.tris = reinterpret_cast<const q4*>(dst + n_nodes16);
+    sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
+  }
   const ShadeParams sp = shade_params(p);
   uint32_t rays_rad = 0, rays_sh = 0;
   if (!compact && blockIdx.x == 0 && threadIdx.x == 0) p.counters[qin ^ 1] = 0u;
@@ -272,11 +289,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
             local++;
           }
           rc.s = hash_sample_index(p, local - 1);
-          const Hit h = trace_ray(p.scene, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth);
+          const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth);
           rays_rad++;
           ShadowRay sr;
           TrainVertex tv;
-          shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
+          shade_hit<GUIDED, TRAIN>(sc, p.guide, sp, rc, ps, h, sr, tv);
           if (TRAIN && tv.valid && p.train) {
             uint32_t idx = atomicAdd(p.train_write_idx, 1u);
             if (p.train_capacity) idx %= p.train_capacity;
@@ -284,7 +301,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
           }
           if (sr.valid) {
             rays_sh++;
-            const Hit o = trace_ray(p.scene, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth);
+            const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth);
             if (o.prim < 0) ps.sum += sr.contrib;
           }
         }
@@ -359,10 +376,16 @@ void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
-  if (p.guiding || p.train)
-    k_bounce<true, true><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qin, bounces, compact);
-  else
-    k_bounce<false, false><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qin, bounces, compact);
+  const size_t scene_bytes = (size_t)p.scene_nodes * 80u + (size_t)p.scene.num_tris * (48u + 96u);
+  const bool lds_scene = p.scene_in_lds && scene_bytes <= 24u * 1024u;
+  const size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
+  if (p.guiding || p.train) {
+    if (lds_scene) k_bounce<true, true, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+    else k_bounce<true, true, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+  } else {
+    if (lds_scene) k_bounce<false, false, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+    else k_bounce<false, false, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+  }
   PT_KCHECK();
 }
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {

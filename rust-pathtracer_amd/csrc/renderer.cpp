@@ -320,6 +320,11 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   p.strict = strict ? 1 : 0;
   p.guiding = (g_guiding_enabled && s.guide_valid) ? 1 : 0;
   p.stack_depth = s.bvh_depth;
+  p.scene_nodes = (uint32_t)s.num_nodes;
+  {
+    static const int lds_scene = getenv("PT_LDS_SCENE") ? atoi(getenv("PT_LDS_SCENE")) : 1;
+    p.scene_in_lds = lds_scene;
+  }
   p.st_o = s.st_o; p.st_d = s.st_d; p.st_s = s.st_s; p.st_m = s.st_m; p.acc = s.acc;
   p.started = s.started;
   p.queue[0] = s.queue[0]; p.queue[1] = s.queue[1];
