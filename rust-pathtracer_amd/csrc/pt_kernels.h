@@ -16,7 +16,9 @@ struct RenderParams {
   CameraView cam;
   int width, height;
   int frame, max_depth;
-  int sample_begin, sample_count;  // this chunk renders global samples [begin, begin+count) per pixel
+  int sample_begin, sample_count;  // this call renders global samples [begin, begin+count) per pixel
+  uint32_t npx;                    // width * height
+  int chunks, chunk_spp;           // the range is split into `chunks` slots per pixel of chunk_spp samples
   int strict;                      // 1: replay the reference's 4-sample launches literally
   int guiding;
   int stack_depth;                 // traversal stack entries per lane
@@ -58,8 +60,8 @@ void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c);
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c);
 
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);
-// out[3p+k] (+)= acc[p].k / divisor(p); mode 0: write mean (divide by started[p]); 1: add raw sums
-void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int mode, hipStream_t s);
+// per pixel, over its `chunks` slots: mode 0 writes the mean (sum / samples), mode 1 adds the raw sums
+void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s);
 // mosaic: raw[p] = max(rgb[3p + ch(p)] / divisor, 0)
 void launch_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float divisor, hipStream_t s);
 

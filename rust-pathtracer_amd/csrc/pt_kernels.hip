@@ -1,10 +1,12 @@
 // pt_kernels.hip -- wavefront path-tracing kernels for gfx950 (MI355X).
 //
-// Work unit: one pixel owns one path slot.  A slot runs its pixel's samples one after the
-// other (the reference's raygen does the same inside one thread, optix_device.cu:953-1053),
-// so the PCG stream of a pixel is consumed in the reference's order.  Queues hold the ids
-// of pixels that still have samples to take; they are compacted with wave64 ballot +
-// popcount and one atomic per wave.
+// Work unit: a path slot = (pixel, sample chunk).  A slot runs its samples one after the other
+// (the reference's raygen does the same inside one thread, optix_device.cu:953-1053), so a
+// chunk's PCG stream is consumed in the reference's order.  With one chunk per pixel a slot is
+// a pixel; converge-mode renders may split a pixel's sample range into a few chunks that run
+// side by side (slot = chunk * npx + pixel), which keeps the GPU full while the pixels with the
+// longest paths finish.  Queues hold the ids of slots that still have samples to take; they
+// are compacted with wave64 ballot + popcount and one atomic per wave.
 //
 // Staged pipeline (one iteration = one bounce of every live path):
 //   generate : fold finished samples into the pixel sums, start the next sample, compact
@@ -64,15 +66,33 @@ __device__ __forceinline__ void store_state(const RenderParams& p, uint32_t px, 
   p.st_m[px] = u4{(uint32_t)s.seed, (uint32_t)(s.seed >> 32), f2u(s.prev_pdf), s.flags};
 }
 
+// A slot id unpacked: which pixel, and which global sample range this slot renders.
+struct Slot {
+  uint32_t pixel;
+  int x, y;
+  int begin;  // global index of the slot's first sample
+  int count;  // samples this slot takes
+};
+__device__ __forceinline__ Slot decode_slot(const RenderParams& p, uint32_t slot) {
+  Slot s;
+  const uint32_t chunk = p.chunks > 1 ? slot / p.npx : 0u;
+  s.pixel = slot - chunk * p.npx;
+  s.y = (int)(s.pixel / (uint32_t)p.width);
+  s.x = (int)(s.pixel - (uint32_t)s.y * (uint32_t)p.width);
+  s.begin = p.sample_begin + (int)chunk * p.chunk_spp;
+  const int rem = p.sample_count - (int)chunk * p.chunk_spp;
+  s.count = rem < p.chunk_spp ? (rem > 0 ? rem : 0) : p.chunk_spp;
+  return s;
+}
 // Sample index fed to the jitter hash, and the PCG state the sample starts from.
 // strict: optix_device.cu:945-948,953 (seed re-derived and s restarted every 4 samples);
 // converge: global index, stream continues (re-seeded at a chunk start).
-__device__ __forceinline__ int hash_sample_index(const RenderParams& p, int local) {
-  return p.strict ? (local & 3) : p.sample_begin + local;
+__device__ __forceinline__ int hash_sample_index(const RenderParams& p, const Slot& sl, int local) {
+  return p.strict ? (local & 3) : sl.begin + local;
 }
-__device__ __forceinline__ uint64_t start_seed(const RenderParams& p, uint32_t pixel, int local, uint64_t carried) {
-  if (p.strict) return (local & 3) == 0 ? pixel_seed(p.frame, pixel) : carried;
-  return local == 0 ? chunk_seed(p.frame, pixel, p.sample_begin) : carried;
+__device__ __forceinline__ uint64_t start_seed(const RenderParams& p, const Slot& sl, int local, uint64_t carried) {
+  if (p.strict) return (local & 3) == 0 ? pixel_seed(p.frame, sl.pixel) : carried;
+  return local == 0 ? chunk_seed(p.frame, sl.pixel, sl.begin) : carried;
 }
 
 // Append `keep` lanes' values to a queue: ballot, one atomic per wave, prefix popcount.
@@ -137,14 +157,14 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
           a.x += s.x; a.y += s.y; a.z += s.z;
           p.acc[pixel] = a;
         }
-        if (local >= p.sample_count) {
+        const Slot sl = decode_slot(p, pixel);
+        if (local >= sl.count) {
           keep = false;
         } else {
-          const int x = (int)(pixel % (uint32_t)p.width), y = (int)(pixel / (uint32_t)p.width);
           const uint64_t carried = ((uint64_t)m.y << 32) | (uint64_t)m.x;
           PathState ps;
-          generate_path(p.cam, x, y, hash_sample_index(p, local), p.frame, p.width, p.height,
-                        start_seed(p, pixel, local, carried), ps);
+          generate_path(p.cam, sl.x, sl.y, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
+                        start_seed(p, sl, local, carried), ps);
           store_state(p, pixel, ps);
           p.started[pixel] = local + 1;
         }
@@ -188,11 +208,12 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       PathState ps = load_state(p, pixel);
       const q4 hq = p.hits[i];
       const Hit h{(int)f2u(hq.x), hq.y, hq.z, hq.w};
+      const Slot sl = decode_slot(p, pixel);
       RandCtx rc;
-      rc.px = (int)(pixel % (uint32_t)p.width);
-      rc.py = (int)(pixel / (uint32_t)p.width);
+      rc.px = sl.x;
+      rc.py = sl.y;
       rc.frame = p.frame;
-      rc.s = ps_dim(ps) < 2u ? hash_sample_index(p, p.started[pixel] - 1) : 0;
+      rc.s = ps_dim(ps) < 2u ? hash_sample_index(p, sl, p.started[pixel] - 1) : 0;
       shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
       store_state(p, pixel, ps);
     }
@@ -269,11 +290,12 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
       pixel = q_in[i];
       PathState ps = load_state(p, pixel);
       int local = p.started[pixel];
-      keep = (ps.flags & (kAlive | kFoldPending)) || local < p.sample_count;
+      const Slot sl = decode_slot(p, pixel);
+      keep = (ps.flags & (kAlive | kFoldPending)) || local < sl.count;
       if (keep) {
         RandCtx rc;
-        rc.px = (int)(pixel % (uint32_t)p.width);
-        rc.py = (int)(pixel / (uint32_t)p.width);
+        rc.px = sl.x;
+        rc.py = sl.y;
         rc.frame = p.frame;
         for (int b = 0; b < bounces; ++b) {
           if (!(ps.flags & kAlive)) {
@@ -283,12 +305,12 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
               p.acc[pixel] = acc;
               ps.flags &= ~kFoldPending;
             }
-            if (local >= p.sample_count) { keep = false; break; }
-            generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, local), p.frame, p.width, p.height,
-                          start_seed(p, pixel, local, ps.seed), ps);
+            if (local >= sl.count) { keep = false; break; }
+            generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
+                          start_seed(p, sl, local, ps.seed), ps);
             local++;
           }
-          rc.s = hash_sample_index(p, local - 1);
+          rc.s = hash_sample_index(p, sl, local - 1);
           const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth);
           rays_rad++;
           ShadowRay sr;
@@ -330,11 +352,16 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
 __global__ void k_iota(uint32_t* dst, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = i;
 }
-__global__ void k_finalize(const q4* acc, const int* started, float* out, uint32_t npx, int mode) {
+__global__ void k_finalize(const q4* acc, const int* started, float* out, uint32_t npx, int chunks, int mode) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const q4 a = acc[i];
+    q4 a = acc[i];
+    int c = started[i];
+    for (int k = 1; k < chunks; ++k) {  // fixed order: results do not depend on scheduling
+      const q4 b = acc[(size_t)k * npx + i];
+      a.x += b.x; a.y += b.y; a.z += b.z;
+      c += started[(size_t)k * npx + i];
+    }
     if (mode == 0) {
-      const int c = started[i];
       const float inv = c > 0 ? 1.0f / (float)c : 0.0f;
       out[3 * i + 0] = a.x * inv; out[3 * i + 1] = a.y * inv; out[3 * i + 2] = a.z * inv;
     } else {
@@ -392,8 +419,8 @@ void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {
   k_iota<<<1024, 256, 0, s>>>(dst, n);
   PT_KCHECK();
 }
-void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int mode, hipStream_t s) {
-  k_finalize<<<1024, 256, 0, s>>>(acc, started, out_rgb, npx, mode);
+void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s) {
+  k_finalize<<<1024, 256, 0, s>>>(acc, started, out_rgb, npx, chunks, mode);
   PT_KCHECK();
 }
 void launch_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float divisor, hipStream_t s) {

@@ -37,6 +37,7 @@ int g_timing_every = 0;
 KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
 int g_fused_bounces = 16;
+constexpr size_t kTargetSlots = 8u << 20;  // path slots worth keeping in flight (pixels x chunks)
 
 int env_choice(const char* name, const char* a, const char* b, int dflt) {
   const char* v = getenv(name);
@@ -49,8 +50,9 @@ int mode() {
   if (g_mode < 0) g_mode = env_choice("PT_MODE", "strict", "converge", PT_MODE_CONVERGE);
   return g_mode;
 }
+// -1 = not chosen by the caller or PT_PIPELINE: pick per scene (see effective_pipeline)
 int pipeline() {
-  if (g_pipeline < 0) g_pipeline = env_choice("PT_PIPELINE", "staged", "fused", PT_PIPELINE_FUSED);
+  if (g_pipeline < 0) g_pipeline = env_choice("PT_PIPELINE", "staged", "fused", -2);
   return g_pipeline;
 }
 int device_index() {
@@ -117,10 +119,19 @@ void set_camera(State& s, const float eye[3], const float lookat[3], const float
   }
 }
 
+// The host-side BVH of the current scene, built once per scene version and shared by every
+// renderer (a resolution change re-creates device state but not the tree).
+BvhBuildResult g_bvh;
+uint64_t g_bvh_version = 0;
+
 void upload_scene(State& s) {
   HostScene& hs = scene();
   const int nt = hs.num_tris();
-  BvhBuildResult bvh = build_bvh8(hs.vertices.data(), hs.indices.data(), nt);
+  if (g_bvh_version != g_scene_version) {
+    g_bvh = build_bvh8(hs.vertices.data(), hs.indices.data(), nt);
+    g_bvh_version = g_scene_version;
+  }
+  const BvhBuildResult& bvh = g_bvh;
   std::vector<ShadeRec> recs((size_t)std::max(nt, 1));
   memset(recs.data(), 0, recs.size() * sizeof(ShadeRec));
   for (int i = 0; i < nt; ++i) {
@@ -229,12 +240,16 @@ State* make_state(int W, int H) {
   HIP_CHECK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
   upload_scene(*s);
   const size_t px = (size_t)W * (size_t)H;
-  s->st_o = dev_alloc<q4>(px); s->st_d = dev_alloc<q4>(px); s->st_s = dev_alloc<q4>(px);
-  s->st_m = dev_alloc<u4>(px); s->acc = dev_alloc<q4>(px); s->hits = dev_alloc<q4>(px);
-  s->sh_o = dev_alloc<q4>(px); s->sh_d = dev_alloc<q4>(px); s->sh_c = dev_alloc<q4>(px);
-  s->started = dev_alloc<int>(px);
-  s->queue[0] = dev_alloc<uint32_t>(px);
-  s->queue[1] = dev_alloc<uint32_t>(px);
+  // A pixel's sample range may be rendered as several chunks side by side (one slot each);
+  // state is sized for the most chunks a render of this resolution will use.
+  s->max_chunks = (int)std::max<size_t>(1, std::min<size_t>(16, kTargetSlots / std::max<size_t>(px, 1)));
+  const size_t slots = px * (size_t)s->max_chunks;
+  s->st_o = dev_alloc<q4>(slots); s->st_d = dev_alloc<q4>(slots); s->st_s = dev_alloc<q4>(slots);
+  s->st_m = dev_alloc<u4>(slots); s->acc = dev_alloc<q4>(slots); s->hits = dev_alloc<q4>(slots);
+  s->sh_o = dev_alloc<q4>(slots); s->sh_d = dev_alloc<q4>(slots); s->sh_c = dev_alloc<q4>(slots);
+  s->started = dev_alloc<int>(slots);
+  s->queue[0] = dev_alloc<uint32_t>(slots);
+  s->queue[1] = dev_alloc<uint32_t>(slots);
   s->counters = dev_alloc<uint32_t>(CNT_WORDS);
   s->ray_counters = dev_alloc<unsigned long long>(2);
   HIP_CHECK(hipMemset(s->ray_counters, 0, 2 * sizeof(unsigned long long)));
@@ -318,6 +333,14 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   p.sample_begin = sample_begin;
   p.sample_count = sample_count;
   p.strict = strict ? 1 : 0;
+  p.npx = (uint32_t)((size_t)s.width * (size_t)s.height);
+  // chunks: strict mode replays one stream per pixel; converge mode splits the range while every
+  // chunk keeps at least 32 samples
+  static const int chunk_override = getenv("PT_CHUNKS") ? atoi(getenv("PT_CHUNKS")) : 0;
+  int chunks = strict ? 1 : (chunk_override > 0 ? std::min(chunk_override, s.max_chunks) : s.max_chunks);
+  while (chunks > 1 && sample_count / chunks < 32) --chunks;
+  p.chunks = std::max(chunks, 1);
+  p.chunk_spp = (sample_count + p.chunks - 1) / p.chunks;
   p.guiding = (g_guiding_enabled && s.guide_valid) ? 1 : 0;
   p.stack_depth = s.bvh_depth;
   p.scene_nodes = (uint32_t)s.num_nodes;
@@ -343,8 +366,9 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
 // enqueued back to back and the live-pixel count is read back once per batch of iterations,
 // one batch behind the GPU, instead of one blocking sync per 4 samples.
 void render_core(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
-  const size_t px = (size_t)s.width * (size_t)s.height;
   RenderParams p = make_params(s, sample_begin, sample_count, max_depth, frame, strict);
+  s.last_chunks = p.chunks;
+  const size_t px = (size_t)p.npx * (size_t)p.chunks;  // path slots
   HIP_CHECK(hipEventRecord(s.ev_begin, s.stream));
   HIP_CHECK(hipMemsetAsync(s.st_m, 0, px * sizeof(u4), s.stream));
   HIP_CHECK(hipMemsetAsync(s.st_s, 0, px * sizeof(q4), s.stream));
@@ -363,7 +387,10 @@ void render_core(State& s, int sample_begin, int sample_count, int max_depth, in
   cfg.blocks = (int)std::min<size_t>((px + 255) / 256, (size_t)s.num_cus * (size_t)std::max(blocks_per_cu, 1));
   cfg.blocks = std::max(cfg.blocks, 1);
   cfg.stream = s.stream;
-  const bool fused = pipeline() == PT_PIPELINE_FUSED;
+  // Small scenes are instruction-bound: keep paths in registers (fused).  Scenes whose BVH lives in
+  // HBM are latency-bound: the lean staged kernels run at twice the occupancy and win.
+  const int chosen = pipeline();
+  const bool fused = chosen >= 0 ? chosen == PT_PIPELINE_FUSED : s.bvh_bytes <= (size_t)(4u << 20);
   const int iters_per_batch = fused ? 8 : 16;
   int qin = 0;
   uint64_t iter = 0;
@@ -419,7 +446,7 @@ int render_mean(State& s, int spp, int max_depth, float noise_threshold, int min
   (void)min_adaptive_samples;
   g_frame++;  // optix_wrapper.cpp:983
   render_core(s, 0, spp, max_depth, g_frame, mode() == PT_MODE_STRICT);
-  launch_finalize(s.acc, s.started, s.d_out_rgb, (uint32_t)((size_t)s.width * (size_t)s.height), 0, s.stream);
+  launch_finalize(s.acc, s.started, s.d_out_rgb, (uint32_t)((size_t)s.width * (size_t)s.height), s.last_chunks, 0, s.stream);
   return 0;
 }
 
@@ -558,7 +585,7 @@ void guiding_reset_train_write_idx(void) {
 void pt_set_mode(int m) { g_mode = m == PT_MODE_STRICT ? PT_MODE_STRICT : PT_MODE_CONVERGE; }
 int pt_get_mode(void) { return mode(); }
 void pt_set_pipeline(int p) { g_pipeline = p == PT_PIPELINE_STAGED ? PT_PIPELINE_STAGED : PT_PIPELINE_FUSED; }
-int pt_get_pipeline(void) { return pipeline(); }
+int pt_get_pipeline(void) { return pipeline() < 0 ? PT_PIPELINE_FUSED : pipeline(); }
 void pt_set_device(int d) {
   if (d != device_index()) {
     delete g_handle;
@@ -577,7 +604,7 @@ int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count
   State& s = ensure_handle(w, h);
   if (!d_sum_rgb) return -1;
   render_core(s, sample_begin, sample_count, max_depth, frame, false);
-  launch_finalize(s.acc, s.started, d_sum_rgb, (uint32_t)((size_t)w * (size_t)h), 1, s.stream);
+  launch_finalize(s.acc, s.started, d_sum_rgb, (uint32_t)((size_t)w * (size_t)h), s.last_chunks, 1, s.stream);
   HIP_CHECK(hipStreamSynchronize(s.stream));
   return 0;
 }

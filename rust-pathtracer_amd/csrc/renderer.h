@@ -38,6 +38,8 @@ struct State {
   int device = 0;
   int width = 0, height = 0;
   int num_cus = 256;
+  int max_chunks = 1;   // slots allocated per pixel
+  int last_chunks = 1;  // chunks used by the most recent render
   hipStream_t stream = nullptr, copy_stream = nullptr;
   CameraView cam{};
   int bayer_pattern = 0;
