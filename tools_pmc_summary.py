@@ -11,7 +11,7 @@ for p in sorted(os.listdir(d)):
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
 for k in tot:
-    if not k.startswith("pt::"): continue
+    if "pt::" not in k: continue
     print(k)
     for c, v in sorted(tot[k].items()):
         print(f"   {c:28s} total {v:16.0f}  per-dispatch {v / max(cnt[k][c],1):14.1f}  dispatches {cnt[k][c]}")
