@@ -39,7 +39,9 @@ extern "C" {
  * top row first, interleaved RGB, linear per-pixel radiance means).  Lazily
  * (re)creates the renderer when (w,h) changes (1087-1100) and increments the
  * global frame counter (983), so consecutive calls use different seeds.
- * noise_threshold == 0 disables adaptive sampling. */
+ * noise_threshold == 0 disables adaptive sampling.  noise_threshold > 0 runs the noise
+ * test of optix_device.cu:1011-1060 in a scheduling-independent form: see
+ * pt_set_adaptive_round below. */
 PT_EXPORT int optix_render_rgb(int w, int h, int spp, int max_depth, float noise_threshold,
                                int min_adaptive_samples, float* out_rgb);
 
@@ -117,6 +119,21 @@ PT_EXPORT int  pt_get_mode(void);
 enum { PT_PIPELINE_STAGED = 0, PT_PIPELINE_FUSED = 1 };
 PT_EXPORT void pt_set_pipeline(int pipeline);
 PT_EXPORT int  pt_get_pipeline(void);
+
+/* Adaptive sampling (noise_threshold > 0).  The reference tests a pixel's noise (relative
+ * standard deviation of luminance and of the CFA channel, maximum over the 3x3 neighbourhood)
+ * after every 4-sample launch once it has min_adaptive_samples, racing with its neighbours
+ * (optix_device.cu:1011-1060, optix_wrapper.cpp:1002-1021).  Here all active pixels run to the
+ * next round boundary, then one pass computes every pixel's noise, a second pass reads the 3x3
+ * maxima and drops the pixels below the threshold.  samples > 0: rounds of that many samples;
+ * samples < 0 (default -32, env PT_ADAPTIVE_ROUND): the first round is -samples and every later
+ * round doubles the count (32, 64, 128, ...); strict mode always uses rounds of 4.  No test runs
+ * before min_adaptive_samples.  The variance covers all samples taken so far.
+ * pt_get_sample_counts copies the last render's per-pixel sample counts (w*h ints, may be
+ * NULL) and the number of rounds it ran (may be NULL; 0 for a non-adaptive render). */
+PT_EXPORT void pt_set_adaptive_round(int samples);
+PT_EXPORT int  pt_get_adaptive_round(void);
+PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
 
 /* Select the HIP device the next renderer is created on (default 0, or env PT_DEVICE). */
 PT_EXPORT void pt_set_device(int device);

@@ -821,7 +821,10 @@ static void raygen(launch_ctx* L, uint32_t dst, uint64_t rays[2]) {
   const int W = a->width, H = a->height;
   const int x = (int)dst % W, y = (int)dst / W;
   const int converge = (a->mode == ORC_CONVERGE);
-  const int batch = 4; /* optix_wrapper.cpp:988-989 */
+  /* optix_wrapper.cpp:988-989 launches 4 samples; adaptive_round > 0 changes the launch size, < 0 makes
+   * the first launch -adaptive_round samples and every later one double the pixel's count */
+  const int batch = a->adaptive_round > 0 ? a->adaptive_round
+                    : (a->adaptive_round < 0 ? (L->sample_counts[dst] == 0 ? -a->adaptive_round : L->sample_counts[dst]) : 4);
 
   float mean_rgb[3] = {L->out_rgb[3 * dst], L->out_rgb[3 * dst + 1], L->out_rgb[3 * dst + 2]};
   float m2_rgb[3] = {0.f, 0.f, 0.f};

@@ -94,6 +94,8 @@ typedef struct {
   int   sample_begin;        /* converge mode: global index of this chunk's first sample */
   int   adaptive_deterministic; /* 1: two-pass 3x3 dilation per launch instead of in-launch atomics */
   int   nthreads;            /* <=0: one thread */
+  int   adaptive_round;      /* samples per launch (optix_wrapper.cpp:988-989 uses 4); 0: 4; <0: first launch
+                              * -adaptive_round samples, each later launch doubles the pixel's count */
   const orc_guide* guide;    /* NULL: no guiding */
   orc_train_sample* train;   /* optional capture ring (single-threaded renders only) */
   uint32_t  train_capacity;

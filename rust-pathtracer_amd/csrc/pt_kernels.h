@@ -30,6 +30,7 @@ struct RenderParams {
   q4* st_s;   // sample sum.xyz, throughput.z
   u4* st_m;   // seed lo, seed hi, prev_pdf bits, flags
   q4* acc;    // per-pixel sum of finished samples (xyz)
+  q4* acc2;   // per-pixel sum of squared sample values (adaptive sampling only, else null)
   int* started;  // samples started per pixel
   // queues
   uint32_t* queue[2];
@@ -58,6 +59,19 @@ void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c);
 // Fused: up to `bounces` bounces per path in registers, regenerating finished samples in place.
 // compact: append survivors to queue qin^1 (the caller swaps), else process queue qin in place.
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c);
+
+// Adaptive sampling: active-pixel lists (ping-pong), the 3x3-dilated noise map and each pixel's own noise.
+struct AdaptiveBuffers {
+  uint32_t* active[2];
+  uint32_t* count;      // one word: length of the list k_noise_select writes (cleared by the caller)
+  uint32_t* noise_map;  // float bits, compared as unsigned (values are >= 0)
+  float* own_noise;
+};
+// One evaluation at a round boundary: reads active[which] (n_active pixels), writes the pixels that stay
+// active to active[which ^ 1] and their number to *count.
+void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, const q4* acc, const q4* acc2,
+                        const int* started, int w, int h, int pattern, int min_samples, int spp, float threshold,
+                        hipStream_t s);
 
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);
 // per pixel, over its `chunks` slots: mode 0 writes the mean (sum / samples), mode 1 adds the raw sums

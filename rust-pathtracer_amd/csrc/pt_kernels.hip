@@ -105,6 +105,13 @@ __device__ __forceinline__ uint32_t wave_append_slot(bool keep, uint32_t* counte
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Adaptive sampling keeps the per-channel sum of squared sample values beside the sum.
+__device__ __forceinline__ void fold_squares(q4* acc2, uint32_t slot, f3 v) {
+  q4 a = acc2[slot];
+  a.x += v.x * v.x; a.y += v.y * v.y; a.z += v.z * v.z;
+  acc2[slot] = a;
+}
+
 __device__ __forceinline__ ShadeParams shade_params(const RenderParams& p) {
   return ShadeParams{p.frame, p.max_depth, p.guiding};
 }
@@ -156,10 +163,13 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
           q4 a = p.acc[pixel];
           a.x += s.x; a.y += s.y; a.z += s.z;
           p.acc[pixel] = a;
+          if (p.acc2) fold_squares(p.acc2, pixel, mk3(s.x, s.y, s.z));
         }
         const Slot sl = decode_slot(p, pixel);
         if (local >= sl.count) {
           keep = false;
+          // the slot may be queued again (next adaptive round): its last sample is folded only once
+          if (m.w & kFoldPending) p.st_m[pixel].w = m.w & ~kFoldPending;
         } else {
           const uint64_t carried = ((uint64_t)m.y << 32) | (uint64_t)m.x;
           PathState ps;
@@ -303,6 +313,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
               q4 acc = p.acc[pixel];
               acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z;
               p.acc[pixel] = acc;
+              if (p.acc2) fold_squares(p.acc2, pixel, ps.sum);
               ps.flags &= ~kFoldPending;
             }
             if (local >= sl.count) { keep = false; break; }
@@ -345,6 +356,76 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
   if ((threadIdx.x & 63u) == 0u) {
     if (rays_rad) atomicAdd(&p.ray_counters[0], (unsigned long long)rays_rad);
     if (rays_sh) atomicAdd(&p.ray_counters[1], (unsigned long long)rays_sh);
+  }
+}
+
+// ------------------------------------------------------------------------- adaptive
+// Deterministic form of the reference's per-launch noise test (optix_device.cu:1011-1060):
+// every pixel that took part in the round computes its own noise from (sum, sum of squares, n),
+// raises the 3x3 neighbourhood of the noise map to it, and -- in a second pass, so that the
+// outcome does not depend on scheduling -- stays active while the 3x3 maximum around it
+// reaches the threshold.  The map is cleared at active pixels only (cuda_kernels.cu:18-25),
+// so a value raised at a pixel that has since stopped persists, as in the reference.
+__device__ __forceinline__ float pixel_noise(q4 s1, q4 s2, int n, int ch) {
+  const float inv_n = 1.0f / (float)n, inv_n1 = 1.0f / (float)(n - 1);
+  const f3 mean = mk3(s1.x * inv_n, s1.y * inv_n, s1.z * inv_n);
+  const f3 var = mk3(fmaxf(s2.x - s1.x * mean.x, 0.f) * inv_n1, fmaxf(s2.y - s1.y * mean.y, 0.f) * inv_n1,
+                     fmaxf(s2.z - s1.z * mean.z, 0.f) * inv_n1);
+  const f3 w = mk3(0.2126f, 0.7152f, 0.0722f);
+  const float noise_rgb = sqrtf(fmaxf(dot(var, w), 0.f)) / fmaxf(dot(mean, w), 1e-6f);
+  const float mean_b = ch == 0 ? mean.x : (ch == 1 ? mean.y : mean.z);
+  const float var_b = ch == 0 ? var.x : (ch == 1 ? var.y : var.z);
+  const float noise_bayer = sqrtf(var_b) / fmaxf(mean_b, 1e-6f);
+  return fmaxf(noise_rgb, noise_bayer);
+}
+__global__ void k_noise_clear(const uint32_t* active, uint32_t n, uint32_t* noise_map) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) noise_map[active[i]] = 0u;
+}
+__global__ void k_noise_raise(const uint32_t* active, uint32_t n, const q4* acc, const q4* acc2, const int* started,
+                              uint32_t* noise_map, float* own_noise, int w, int h, int pattern, int min_samples) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t px = active[i];
+    const int cnt = started[px];
+    float noise = -1.0f;
+    if (cnt >= min_samples && cnt > 1) {
+      const int y = (int)(px / (uint32_t)w), x = (int)(px - (uint32_t)y * (uint32_t)w);
+      noise = pixel_noise(acc[px], acc2[px], cnt, bayer_channel_for(x, y, pattern));
+      const uint32_t bits = f2u(noise);  // noise >= 0: float order == unsigned order of the bits
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = x + dx, yy = y + dy;
+          if (xx < 0 || yy < 0 || xx >= w || yy >= h) continue;
+          atomicMax(&noise_map[(size_t)yy * (size_t)w + (size_t)xx], bits);
+        }
+    }
+    own_noise[px] = noise;
+  }
+}
+__global__ void __launch_bounds__(256) k_noise_select(const uint32_t* active, uint32_t n, const uint32_t* noise_map,
+                                                      const float* own_noise, const int* started, int w, int h, int spp,
+                                                      float threshold, uint32_t* out, uint32_t* out_count) {
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    bool keep = false;
+    uint32_t px = 0;
+    if (i < n) {
+      px = active[i];
+      const float own = own_noise[px];
+      keep = started[px] < spp;
+      if (own >= 0.f) {
+        const int y = (int)(px / (uint32_t)w), x = (int)(px - (uint32_t)y * (uint32_t)w);
+        float mx = own;
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx, yy = y + dy;
+            if (xx < 0 || yy < 0 || xx >= w || yy >= h) continue;
+            mx = fmaxf(mx, u2f(noise_map[(size_t)yy * (size_t)w + (size_t)xx]));
+          }
+        keep = keep && mx >= threshold;
+      }
+    }
+    const uint32_t slot = wave_append_slot(keep, out_count);
+    if (keep) out[slot] = px;
   }
 }
 
@@ -417,6 +498,20 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, con
 }
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {
   k_iota<<<1024, 256, 0, s>>>(dst, n);
+  PT_KCHECK();
+}
+void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, const q4* acc, const q4* acc2,
+                        const int* started, int w, int h, int pattern, int min_samples, int spp, float threshold,
+                        hipStream_t s) {
+  const int blocks = (int)((n_active + 255u) / 256u < 2048u ? (n_active + 255u) / 256u : 2048u);
+  if (blocks <= 0) return;
+  k_noise_clear<<<blocks, 256, 0, s>>>(a.active[which], n_active, a.noise_map);
+  PT_KCHECK();
+  k_noise_raise<<<blocks, 256, 0, s>>>(a.active[which], n_active, acc, acc2, started, a.noise_map, a.own_noise, w, h,
+                                       pattern, min_samples);
+  PT_KCHECK();
+  k_noise_select<<<blocks, 256, 0, s>>>(a.active[which], n_active, a.noise_map, a.own_noise, started, w, h, spp, threshold,
+                                        a.active[which ^ 1], a.count);
   PT_KCHECK();
 }
 void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s) {

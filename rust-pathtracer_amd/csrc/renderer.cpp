@@ -37,6 +37,7 @@ int g_timing_every = 0;
 KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
 int g_fused_bounces = 16;
+int g_adaptive_round = getenv("PT_ADAPTIVE_ROUND") ? atoi(getenv("PT_ADAPTIVE_ROUND")) : -32;
 constexpr size_t kTargetSlots = 8u << 20;  // path slots worth keeping in flight (pixels x chunks)
 
 int env_choice(const char* name, const char* a, const char* b, int dflt) {
@@ -253,7 +254,7 @@ State* make_state(int W, int H) {
   s->counters = dev_alloc<uint32_t>(CNT_WORDS);
   s->ray_counters = dev_alloc<unsigned long long>(2);
   HIP_CHECK(hipMemset(s->ray_counters, 0, 2 * sizeof(unsigned long long)));
-  HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), 2 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), 3 * CNT_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   s->d_out_rgb = dev_alloc<float>(px * 3);
   s->d_out_bayer = dev_alloc<float>(px);
   for (int i = 0; i < 2; ++i) HIP_CHECK(hipEventCreateWithFlags(&s->ev_slot[i], hipEventDisableTiming));
@@ -363,56 +364,64 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
 }
 
 // The batch loop (optix_wrapper.cpp:1002-1021) re-thought for a wavefront: iterations are
-// enqueued back to back and the live-pixel count is read back once per batch of iterations,
+// enqueued back to back and the live-slot count is read back once per batch of iterations,
 // one batch behind the GPU, instead of one blocking sync per 4 samples.
-void render_core(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
-  RenderParams p = make_params(s, sample_begin, sample_count, max_depth, frame, strict);
-  s.last_chunks = p.chunks;
-  const size_t px = (size_t)p.npx * (size_t)p.chunks;  // path slots
-  HIP_CHECK(hipEventRecord(s.ev_begin, s.stream));
-  HIP_CHECK(hipMemsetAsync(s.st_m, 0, px * sizeof(u4), s.stream));
-  HIP_CHECK(hipMemsetAsync(s.st_s, 0, px * sizeof(q4), s.stream));
-  HIP_CHECK(hipMemsetAsync(s.acc, 0, px * sizeof(q4), s.stream));
-  HIP_CHECK(hipMemsetAsync(s.started, 0, px * sizeof(int), s.stream));
-  launch_iota(s.queue[0], (uint32_t)px, s.stream);
-  uint32_t init_counters[CNT_WORDS] = {0};
-  init_counters[CNT_Q0] = (uint32_t)px;
-  HIP_CHECK(hipMemcpyAsync(s.counters, init_counters, sizeof(init_counters), hipMemcpyHostToDevice, s.stream));
-  HIP_CHECK(hipStreamSynchronize(s.stream));  // init_counters is a stack buffer
-
+struct RenderLoop {
+  State& s;
+  RenderParams p;
   LaunchCfg cfg;
-  cfg.threads = 256;
-  static const int blocks_per_cu = getenv("PT_BLOCKS_PER_CU") ? atoi(getenv("PT_BLOCKS_PER_CU")) : 16;
-  static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
-  cfg.blocks = (int)std::min<size_t>((px + 255) / 256, (size_t)s.num_cus * (size_t)std::max(blocks_per_cu, 1));
-  cfg.blocks = std::max(cfg.blocks, 1);
-  cfg.stream = s.stream;
-  // Small scenes are instruction-bound: keep paths in registers (fused).  Scenes whose BVH lives in
-  // HBM are latency-bound: the lean staged kernels run at twice the occupancy and win.
-  const int chosen = pipeline();
-  const bool fused = chosen >= 0 ? chosen == PT_PIPELINE_FUSED : s.bvh_bytes <= (size_t)(4u << 20);
-  const int iters_per_batch = fused ? 8 : 16;
-  int qin = 0;
+  bool fused;
   uint64_t iter = 0;
-  int slot = 0;
-  bool have_prev = false;
-  if (sample_count > 0) {
+
+  RenderLoop(State& st, const RenderParams& params) : s(st), p(params) {
+    const size_t slots = (size_t)p.npx * (size_t)p.chunks;
+    cfg.threads = 256;
+    static const int blocks_per_cu = getenv("PT_BLOCKS_PER_CU") ? atoi(getenv("PT_BLOCKS_PER_CU")) : 16;
+    cfg.blocks = (int)std::min<size_t>((slots + 255) / 256, (size_t)s.num_cus * (size_t)std::max(blocks_per_cu, 1));
+    cfg.blocks = std::max(cfg.blocks, 1);
+    cfg.stream = s.stream;
+    // Small scenes are instruction-bound: keep paths in registers (fused).  Scenes whose BVH lives in
+    // HBM are latency-bound: the lean staged kernels run at twice the occupancy and win.
+    const int chosen = pipeline();
+    fused = chosen >= 0 ? chosen == PT_PIPELINE_FUSED : s.bvh_bytes <= (size_t)(4u << 20);
+  }
+
+  // Clear the per-slot state of a new render.
+  void reset_slots() {
+    const size_t slots = (size_t)p.npx * (size_t)p.chunks;
+    HIP_CHECK(hipMemsetAsync(s.st_m, 0, slots * sizeof(u4), s.stream));
+    HIP_CHECK(hipMemsetAsync(s.st_s, 0, slots * sizeof(q4), s.stream));
+    HIP_CHECK(hipMemsetAsync(s.acc, 0, slots * sizeof(q4), s.stream));
+    HIP_CHECK(hipMemsetAsync(s.started, 0, slots * sizeof(int), s.stream));
+    if (p.acc2) HIP_CHECK(hipMemsetAsync(p.acc2, 0, slots * sizeof(q4), s.stream));
+  }
+
+  // Queue 0 holds `n` slot ids (already written on the stream); run until every slot has finished.
+  void drain(uint32_t n) {
+    if (n == 0) return;
+    uint32_t* init = s.h_counters + 2 * CNT_WORDS;  // pinned staging, third slot
+    memset(init, 0, CNT_WORDS * sizeof(uint32_t));
+    init[CNT_Q0] = n;
+    HIP_CHECK(hipMemcpyAsync(s.counters, init, CNT_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+    static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
+    const int iters_per_batch = fused ? 8 : 16;
+    int qin = 0, slot = 0;
+    bool have_prev = false;
     for (;;) {
       for (int b = 0; b < iters_per_batch; ++b, ++iter) {
         const bool timed = g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
         if (fused) {
-          // compact the pixel queue on the last launch of a batch only: finished pixels are rare
+          // compact the slot queue on the last launch of a batch only: finished slots are rare
           const int compact = (b == iters_per_batch - 1) ? 1 : 0;
           Timer t(s, PT_K_BOUNCE, timed, 0);
           launch_bounce(p, qin, std::max(fused_bounces, 1), compact, cfg);
           if (compact) qin ^= 1;
           continue;
-        } else {
-          { Timer t(s, PT_K_GENERATE, timed, 0); launch_generate(p, qin, cfg); }
-          { Timer t(s, PT_K_EXTEND, timed, 0); launch_extend(p, qin ^ 1, cfg); }
-          { Timer t(s, PT_K_SHADE, timed, 0); launch_shade(p, qin ^ 1, cfg); }
-          { Timer t(s, PT_K_OCCLUDE, timed, 0); launch_occlude(p, qin, cfg); }
         }
+        { Timer t(s, PT_K_GENERATE, timed, 0); launch_generate(p, qin, cfg); }
+        { Timer t(s, PT_K_EXTEND, timed, 0); launch_extend(p, qin ^ 1, cfg); }
+        { Timer t(s, PT_K_SHADE, timed, 0); launch_shade(p, qin ^ 1, cfg); }
+        { Timer t(s, PT_K_OCCLUDE, timed, 0); launch_occlude(p, qin, cfg); }
         qin ^= 1;
       }
       HIP_CHECK(hipMemcpyAsync(s.h_counters + slot * CNT_WORDS, s.counters, CNT_WORDS * sizeof(uint32_t),
@@ -428,24 +437,101 @@ void render_core(State& s, int sample_begin, int sample_count, int max_depth, in
       slot ^= 1;
     }
   }
-  HIP_CHECK(hipEventRecord(s.ev_end, s.stream));
-  HIP_CHECK(hipStreamSynchronize(s.stream));
-  float ms = 0.f;
-  HIP_CHECK(hipEventElapsedTime(&ms, s.ev_begin, s.ev_end));
-  s.last_render_ms = ms;
-  resolve_timers(s);
-  unsigned long long rc[2];
-  HIP_CHECK(hipMemcpy(rc, s.ray_counters, sizeof(rc), hipMemcpyDeviceToHost));
-  g_rays_total[0] += rc[0];
-  g_rays_total[1] += rc[1];
-  HIP_CHECK(hipMemset(s.ray_counters, 0, sizeof(rc)));
+
+  void begin() { HIP_CHECK(hipEventRecord(s.ev_begin, s.stream)); }
+  void end() {
+    HIP_CHECK(hipEventRecord(s.ev_end, s.stream));
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, s.ev_begin, s.ev_end));
+    s.last_render_ms = ms;
+    resolve_timers(s);
+    unsigned long long rc[2];
+    HIP_CHECK(hipMemcpy(rc, s.ray_counters, sizeof(rc), hipMemcpyDeviceToHost));
+    g_rays_total[0] += rc[0];
+    g_rays_total[1] += rc[1];
+    HIP_CHECK(hipMemset(s.ray_counters, 0, sizeof(rc)));
+  }
+};
+
+void render_core(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
+  RenderLoop loop(s, make_params(s, sample_begin, sample_count, max_depth, frame, strict));
+  s.last_chunks = loop.p.chunks;
+  s.adaptive_rounds = 0;
+  const size_t slots = (size_t)loop.p.npx * (size_t)loop.p.chunks;
+  loop.begin();
+  loop.reset_slots();
+  launch_iota(s.queue[0], (uint32_t)slots, s.stream);
+  if (sample_count > 0) loop.drain((uint32_t)slots);
+  loop.end();
+}
+
+// Adaptive sampling (optix_wrapper.cpp:1002-1021 with optix_device.cu:1011-1060), made independent of
+// scheduling: all active pixels take `round` samples, then the noise test runs as its own pass and
+// compacts the active list.  The first test happens at the first round boundary at or past
+// min_adaptive_samples.  One slot per pixel; the variance estimate covers all samples so far.
+void ensure_adaptive(State& s) {
+  if (s.acc2) return;
+  const size_t px = (size_t)s.width * (size_t)s.height;
+  s.acc2 = dev_alloc<q4>(px);
+  s.adaptive.active[0] = dev_alloc<uint32_t>(px);
+  s.adaptive.active[1] = dev_alloc<uint32_t>(px);
+  s.adaptive.count = dev_alloc<uint32_t>(1);
+  s.adaptive.noise_map = dev_alloc<uint32_t>(px);
+  s.adaptive.own_noise = dev_alloc<float>(px);
+}
+
+void render_adaptive(State& s, int spp, int max_depth, int frame, bool strict, float threshold, int min_samples) {
+  ensure_adaptive(s);
+  RenderParams p = make_params(s, 0, spp, max_depth, frame, strict);
+  p.chunks = 1;
+  p.chunk_spp = spp;
+  p.acc2 = s.acc2;
+  RenderLoop loop(s, p);
+  s.last_chunks = 1;
+  const uint32_t npx = p.npx;
+  // strict mode replays the reference's 4-sample launches, so it is tested at that cadence
+  const bool doubling = !strict && g_adaptive_round < 0;
+  const int round = strict ? 4 : std::max(std::abs(g_adaptive_round), 1);
+  auto next_target = [&](int d) { return doubling ? (d == 0 ? round : 2 * d) : d + round; };
+  loop.begin();
+  loop.reset_slots();
+  HIP_CHECK(hipMemsetAsync(s.adaptive.noise_map, 0, (size_t)npx * sizeof(uint32_t), s.stream));
+  launch_iota(s.adaptive.active[0], npx, s.stream);
+  uint32_t n_active = npx;
+  int which = 0, done = 0;
+  s.adaptive_rounds = 0;
+  while (n_active > 0 && done < spp) {
+    int target = next_target(done);
+    while (target < min_samples && target < spp) target = next_target(target);  // no test before min_samples
+    target = std::min(target, spp);
+    loop.p.sample_count = target;
+    loop.p.chunk_spp = target;
+    HIP_CHECK(hipMemcpyAsync(s.queue[0], s.adaptive.active[which], (size_t)n_active * sizeof(uint32_t),
+                             hipMemcpyDeviceToDevice, s.stream));
+    loop.drain(n_active);
+    done = target;
+    s.adaptive_rounds++;
+    if (done >= spp) break;
+    HIP_CHECK(hipMemsetAsync(s.adaptive.count, 0, sizeof(uint32_t), s.stream));
+    launch_noise_round(s.adaptive, which, n_active, s.acc, s.acc2, s.started, s.width, s.height, s.bayer_pattern,
+                       min_samples, spp, threshold, s.stream);
+    HIP_CHECK(hipMemcpyAsync(s.h_counters + 2 * CNT_WORDS, s.adaptive.count, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             s.stream));
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    n_active = s.h_counters[2 * CNT_WORDS];
+    which ^= 1;
+  }
+  loop.end();
 }
 
 int render_mean(State& s, int spp, int max_depth, float noise_threshold, int min_adaptive_samples) {
-  (void)noise_threshold;
-  (void)min_adaptive_samples;
   g_frame++;  // optix_wrapper.cpp:983
-  render_core(s, 0, spp, max_depth, g_frame, mode() == PT_MODE_STRICT);
+  const bool strict = mode() == PT_MODE_STRICT;
+  if (noise_threshold > 0.0f && spp > 0)
+    render_adaptive(s, spp, max_depth, g_frame, strict, noise_threshold, min_adaptive_samples);
+  else
+    render_core(s, 0, spp, max_depth, g_frame, strict);
   launch_finalize(s.acc, s.started, s.d_out_rgb, (uint32_t)((size_t)s.width * (size_t)s.height), s.last_chunks, 0, s.stream);
   return 0;
 }
@@ -476,6 +562,8 @@ State::~State() {
   dev_free(st_o); dev_free(st_d); dev_free(st_s); dev_free(st_m); dev_free(acc); dev_free(hits);
   dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started);
   dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
+  dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
+  dev_free(adaptive.noise_map); dev_free(adaptive.own_noise);
   dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_demosaic_tmp);
   dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid);
   if (h_counters) (void)hipHostFree(h_counters);
@@ -671,6 +759,26 @@ void pt_get_kernel_stats(int kernel, double* total_ms, uint64_t* timed_launches,
 }
 void pt_reset_kernel_stats(void) {
   for (KernelStat& k : g_kstats) k = KernelStat();
+}
+void pt_set_adaptive_round(int samples) { g_adaptive_round = samples != 0 ? samples : -32; }
+int pt_get_adaptive_round(void) { return g_adaptive_round; }
+int pt_get_sample_counts(int* out_counts, int* out_rounds) {
+  if (!g_handle) return -1;
+  State& s = *g_handle;
+  HIP_CHECK(hipSetDevice(s.device));
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  const size_t px = (size_t)s.width * (size_t)s.height;
+  if (out_counts) {
+    std::vector<int> tmp(px * (size_t)s.last_chunks);
+    HIP_CHECK(hipMemcpy(tmp.data(), s.started, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < px; ++i) {
+      int c = 0;
+      for (int k = 0; k < s.last_chunks; ++k) c += tmp[(size_t)k * px + i];
+      out_counts[i] = c;
+    }
+  }
+  if (out_rounds) *out_rounds = s.adaptive_rounds;
+  return 0;
 }
 double pt_last_render_ms(void) { return g_handle ? g_handle->last_render_ms : 0.0; }
 

@@ -61,9 +61,14 @@ struct State {
   uint32_t* queue[2] = {nullptr, nullptr};
   uint32_t* counters = nullptr;
   unsigned long long* ray_counters = nullptr;
-  uint32_t* h_counters = nullptr;  // pinned, 2 slots x CNT_WORDS
+  uint32_t* h_counters = nullptr;  // pinned, 3 slots x CNT_WORDS (two read-back slots, one staging)
   hipEvent_t ev_slot[2] = {nullptr, nullptr};
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+  // adaptive sampling (allocated on first use)
+  q4* acc2 = nullptr;
+  AdaptiveBuffers adaptive{};
+  int adaptive_rounds = 0;
 
   // outputs
   float* d_out_rgb = nullptr;

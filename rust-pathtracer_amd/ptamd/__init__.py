@@ -92,6 +92,9 @@ SIGNATURES = {
     "pt_get_kernel_stats": (None, [C.c_int, C.POINTER(C.c_double), _u64p, _u64p, _u64p]),
     "pt_reset_kernel_stats": (None, []),
     "pt_last_render_ms": (C.c_double, []),
+    "pt_set_adaptive_round": (None, [C.c_int]),
+    "pt_get_adaptive_round": (C.c_int, []),
+    "pt_get_sample_counts": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pt_scene_cornell": (None, []),
     "pt_scene_synthetic": (None, [C.c_uint32, C.c_int, C.c_int]),
     "pt_scene_triangles": (None, [_fp, C.c_int, _u32p, C.c_int, _fp]),
@@ -187,6 +190,16 @@ def read_exr(path):
     if rc != 0:
         raise RuntimeError(f"pt_read_exr: {rc}")
     return out
+
+
+def sample_counts(w, h):
+    """Per-pixel sample counts of the last render and the number of adaptive rounds it ran."""
+    counts = np.zeros((h, w), np.int32)
+    rounds = C.c_int(0)
+    rc = lib().pt_get_sample_counts(counts.ctypes.data_as(C.POINTER(C.c_int)), C.byref(rounds))
+    if rc != 0:
+        raise RuntimeError("pt_get_sample_counts: no renderer")
+    return counts, rounds.value
 
 
 def ray_counts():

@@ -58,7 +58,7 @@ class RenderArgs(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("spp", C.c_int), ("max_depth", C.c_int),
                 ("frame", C.c_int), ("bayer_pattern", C.c_int), ("noise_threshold", C.c_float),
                 ("min_adaptive_samples", C.c_int), ("mode", C.c_int), ("sample_begin", C.c_int),
-                ("adaptive_deterministic", C.c_int), ("nthreads", C.c_int),
+                ("adaptive_deterministic", C.c_int), ("nthreads", C.c_int), ("adaptive_round", C.c_int),
                 ("guide", C.POINTER(Guide)), ("train", C.POINTER(TrainSample)),
                 ("train_capacity", C.c_uint32), ("train_write_idx", C.POINTER(C.c_uint32))]
 
@@ -178,13 +178,13 @@ def make_guide(regions, lobes, grid_res):
 
 
 def render(width, height, spp, max_depth=32, frame=1, pattern=0, noise_threshold=0.0, min_adaptive=32,
-           mode=CONVERGE, sample_begin=0, adaptive_deterministic=0, nthreads=0, guide=None):
+           mode=CONVERGE, sample_begin=0, adaptive_deterministic=0, nthreads=0, guide=None, adaptive_round=0):
     """Returns (rgb[h,w,3], bayer[h,w], counts[h,w], (radiance_rays, shadow_rays))."""
     L = lib()
     if nthreads <= 0:
         nthreads = os.cpu_count() or 1
     a = RenderArgs(width, height, spp, max_depth, frame, pattern, noise_threshold, min_adaptive, mode,
-                   sample_begin, adaptive_deterministic, nthreads,
+                   sample_begin, adaptive_deterministic, nthreads, adaptive_round,
                    C.pointer(guide) if guide is not None else None, None, 0, None)
     rgb = np.zeros((height, width, 3), np.float32)
     bayer = np.zeros((height, width), np.float32)

@@ -438,6 +438,63 @@ def test_sample_chunks_sum_like_ranks(gpu):
     assert r[0, 0] == pytest.approx(max(both[0, 0, 2] / 16, 0), rel=1e-6)  # BGGR: (0,0) is blue
 
 
+# ------------------------------------------------------------------ adaptive sampling
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_adaptive_sampling_matches_oracle(gpu, oracle, pipeline):
+    """noise_threshold > 0: same round cadence and noise test as the oracle's scheduling-independent
+    restatement of optix_device.cu:1011-1060; per-pixel sample counts agree except where a noise value
+    sits on the threshold, and the image stays within the tolerance of a full-spp render."""
+    L = gpu.lib()
+    w, h, spp, thr, mn, rnd = 96, 32, 256, 1.5, 32, 32
+    L.pt_set_pipeline(pipeline)
+    L.pt_set_mode(gpu.MODE_CONVERGE)
+    L.pt_set_adaptive_round(rnd)
+    L.pt_set_frame(0)
+    L.pt_reset_ray_counts()
+    img = gpu.render_rgb(w, h, spp, noise_threshold=thr, min_adaptive_samples=mn)
+    counts, rounds = gpu.sample_counts(w, h)
+    rr, rs = gpu.ray_counts()
+    o_img, _, o_counts, o_rays = oracle.render(w, h, spp, frame=1, noise_threshold=thr, min_adaptive=mn,
+                                               mode=oracle.CONVERGE, adaptive_deterministic=1, adaptive_round=rnd)
+    assert counts.min() >= mn and counts.max() <= spp and (counts % rnd == 0).all()
+    assert 1 < rounds <= spp // rnd
+    assert len(np.unique(counts)) > 2  # it adapts: neither all-min nor all-max
+    # black side bars stop at the first test (their noise is 0)
+    assert (counts[:, 0] == mn).all() and (o_counts[:, 0] == mn).all()
+    same = (counts == o_counts).mean()
+    assert same > 0.7, same
+    assert abs(counts.mean() - o_counts.mean()) / o_counts.mean() < 0.05
+    assert abs((rr + rs) - sum(o_rays)) / sum(o_rays) < 0.05
+    assert abs(img.mean() - o_img.mean()) / o_img.mean() < 0.05  # early stops make the mean firefly-sensitive
+    close = (np.abs(img - o_img) <= 2e-3 + 2e-2 * np.abs(o_img)).all(axis=2).mean()
+    assert close > 0.6, close
+    # doubling rounds (the default): 32, 64, 128, 256
+    L.pt_set_adaptive_round(-32)
+    L.pt_set_frame(0)
+    gpu.render_rgb(w, h, spp, noise_threshold=thr, min_adaptive_samples=mn)
+    c2, r2 = gpu.sample_counts(w, h)
+    o2 = oracle.render(w, h, spp, frame=1, noise_threshold=thr, min_adaptive=mn, mode=oracle.CONVERGE,
+                       adaptive_deterministic=1, adaptive_round=-32)[2]
+    assert set(np.unique(c2)) <= {32, 64, 128, 256} and r2 <= 4
+    assert (c2 == o2).mean() > 0.7
+    L.pt_set_adaptive_round(rnd)
+    # threshold so high that every pixel stops at the first test; so low that none stops
+    L.pt_set_frame(0)
+    gpu.render_rgb(w, h, spp, noise_threshold=1e9, min_adaptive_samples=mn)
+    c_hi, r_hi = gpu.sample_counts(w, h)
+    assert (c_hi == mn).all() and r_hi == 1
+    L.pt_set_frame(0)
+    full = gpu.render_rgb(w, h, 48, noise_threshold=1e-9, min_adaptive_samples=mn)
+    c_lo, _ = gpu.sample_counts(w, h)
+    assert (c_lo[:, w // 2] == 48).all() and (c_lo[:, 0] == mn).all()
+    L.pt_set_frame(0)
+    plain = gpu.render_rgb(w, h, 48)  # below 64 spp a pixel is one slot, as in an adaptive render
+    lit = c_lo == 48  # pixels that never stopped took exactly the plain render's samples
+    assert np.allclose(full[lit], plain[lit], rtol=1e-5, atol=1e-6)
+    c_plain, r_plain = gpu.sample_counts(w, h)
+    assert (c_plain == 48).all() and r_plain == 0
+
+
 # ------------------------------------------------------------------ a16 / a17 demosaic + EXR
 @pytest.mark.parametrize("algo,name", [(0, "amaze"), (1, "bilinear")])
 def test_demosaic_bit_exact(gpu, oracle, algo, name):
