@@ -176,6 +176,10 @@ PT_EXPORT void pt_set_kernel_timing(int every_nth_launch);
 PT_EXPORT void pt_get_kernel_stats(int kernel, double* total_ms, uint64_t* timed_launches, uint64_t* launches,
                                    uint64_t* work_items);
 PT_EXPORT void pt_reset_kernel_stats(void);
+/* Section counters of a library built with -DPT_PROFILE (make prof): out64[2k] = times a wave ran
+ * section k of the fused kernel, out64[2k+1] = active lanes summed over those; cleared by the call.
+ * out64 holds 64 words.  Returns the number of sections, 0 from the shipped build. */
+PT_EXPORT int pt_dbg_profile_counters(uint64_t* out64);
 /* Wall time of the device work of the last render call (HIP events around the whole loop). */
 PT_EXPORT double pt_last_render_ms(void);
 

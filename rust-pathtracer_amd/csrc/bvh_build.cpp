@@ -188,14 +188,34 @@ struct Emitter {
   BvhBuildResult& out;
   uint32_t tri_cursor = 0;
 
+  // traversal record of a triangle (layout: TriRecord comment in pt_bvh.h), computed in double
   void write_tri(uint32_t slot_index, uint32_t prim) {
     const uint32_t* t = b.idx + 3 * (size_t)prim;
-    for (int k = 0; k < 3; ++k) {
-      const float* v = b.verts + 3 * (size_t)t[k];
-      q4 q{v[0], v[1], v[2], 0.f};
-      if (k == 0) q.w = u2f(prim);
-      out.tris[3 * (size_t)slot_index + k] = q;
-    }
+    double v[3][3];
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c) v[k][c] = (double)b.verts[3 * (size_t)t[k] + c];
+    const double e1[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
+    const double e2[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    q4* q = &out.tris[4 * (size_t)slot_index];
+    q[0] = q4{(float)v[0][0], (float)v[0][1], (float)v[0][2], 0.f};
+    q[1] = q4{0.f, 0.f, 0.f, u2f(prim)};
+    q[2] = q4{0.f, 0.f, 0.f, 0.f};
+    q[3] = q4{0.f, 0.f, 0.f, 0.f};
+    if (!(nn > 0.0) || !std::isfinite(nn)) return;  // degenerate: a zero normal makes t = nan, never hit
+    const double inv = 1.0 / nn, invlen = 1.0 / std::sqrt(nn);
+    // r1 = (e2 x n) / n.n, r2 = (n x e1) / n.n
+    const double r1[3] = {(e2[1] * n[2] - e2[2] * n[1]) * inv, (e2[2] * n[0] - e2[0] * n[2]) * inv, (e2[0] * n[1] - e2[1] * n[0]) * inv};
+    const double r2[3] = {(n[1] * e1[2] - n[2] * e1[1]) * inv, (n[2] * e1[0] - n[0] * e1[2]) * inv, (n[0] * e1[1] - n[1] * e1[0]) * inv};
+    const double norm1 = std::fabs(r1[0]) + std::fabs(r1[1]) + std::fabs(r1[2]);
+    const double norm2 = std::fabs(r2[0]) + std::fabs(r2[1]) + std::fabs(r2[2]);
+    // 16 ulps of the largest term of the dot products per unit of coordinate magnitude, both rows
+    const double eps = std::ldexp(norm1 + norm2, -20);
+    q[0].w = (float)eps;
+    q[1].x = (float)r1[0]; q[1].y = (float)r1[1]; q[1].z = (float)r1[2];
+    q[2].x = (float)r2[0]; q[2].y = (float)r2[1]; q[2].z = (float)r2[2];
+    q[3].x = (float)(n[0] * invlen); q[3].y = (float)(n[1] * invlen); q[3].z = (float)(n[2] * invlen);
   }
 
   // returns the number of internal-node levels below and including this node
@@ -348,6 +368,7 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
     Box bx;
     bx.reset();
     for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)t + k]);
+    for (int k = 0; k < 3; ++k) out.vmag = std::max(out.vmag, std::max(std::fabs(bx.lo[k]), std::fabs(bx.hi[k])));
     for (int k = 0; k < 3; ++k) {
       b.centroid[3 * (size_t)t + k] = 0.5f * (bx.lo[k] + bx.hi[k]);
       // pad so that rays grazing a flat or grid-aligned box are not lost to rounding
@@ -361,7 +382,7 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   const int root2 = b.build2(0, num_tris);
   b.dp.resize(b.nodes2.size());
   b.compute_collapse(root2);
-  out.tris.resize(3 * (size_t)num_tris);
+  out.tris.resize(4 * (size_t)num_tris);
   out.nodes.reserve((size_t)num_tris / 2 + 16);
   out.nodes.resize(1);
   Emitter em{b, out};

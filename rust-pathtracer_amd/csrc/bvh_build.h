@@ -12,7 +12,8 @@ namespace pt {
 
 struct BvhBuildResult {
   std::vector<BvhNode> nodes;  // node 0 is the root
-  std::vector<q4> tris;        // 3 x q4 per triangle in leaf order; tris[3i].w = primitive index bits
+  std::vector<q4> tris;        // 4 x q4 per triangle in leaf order (traversal records, see pt_bvh.h)
+  float vmag = 0.f;            // largest |coordinate| of any referenced vertex
   int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
   int num_tris = 0;
 };

@@ -10,6 +10,9 @@
 
 namespace pt {
 
+PT_HD f3 ldq(const q4& q) { return mk3(q.x, q.y, q.z); }
+PT_HD f3 ldv(const q4& q) { return mk3(q.x, q.y, q.z); }
+
 struct Hit {
   int prim;  // -1: miss
   float t, b1, b2;
@@ -100,6 +103,47 @@ PT_HD bool intersect_triangle(const RayShear& rs, f3 o, f3 v0, f3 v1, f3 v2, flo
   return true;
 }
 
+// Traversal copy of a triangle, 64 bytes: a precomputed affine map to "unit triangle" space.
+//   q0 = v0.xyz, eps     q1 = r1.xyz, primitive index bits     q2 = r2.xyz, -     q3 = n.xyz, -
+// r1, r2 are the dual basis of the edges (r1.(v1-v0) = 1, r1.(v2-v0) = 0, ...), n the unit normal,
+// so for a point p: b1 = r1.(p-v0), b2 = r2.(p-v0), distance from the plane = n.(p-v0).
+// eps bounds the rounding error of b1, b2 per unit of coordinate magnitude.
+constexpr int kTriWords = 4;
+
+// Fast ray/triangle test: solve for t on the plane, evaluate the barycentrics directly.  It decides
+// alone only when the hit point is clearly inside or clearly outside; a point within the error band
+// of an edge goes to the watertight test on the original vertices (intersect_triangle), so shared
+// edges and vertices keep the watertight test's answer and no ray slips between two triangles.
+// Returns 0 miss, 1 hit (hit updated), 2 undecided.
+PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, f3 o, f3 d, float rmag, float tmin,
+                        Hit& hit) {
+  // every kernel must get the same bits out of this test: products and sums are fused only where written
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  const f3 A = o - ldq(q0);
+  const f3 n = ldq(q3);
+  const float t = -shear_dot(n, A) * rcp(shear_dot(n, d));  // parallel ray: t is inf or nan and the next test fails
+  // slack: a few ulps of the coordinates involved.  A ray that starts on the plane itself (t ~ tmin) is
+  // the watertight test's call too: its answer there is decided by its own rounding.
+  const float slack = 9.5367431640625e-7f * (rmag + fabsf(t));
+  if (!(t + slack > tmin) || !(t - slack < hit.t)) return 0;
+  const f3 r1 = ldq(q1), r2 = ldq(q2);
+  const float b1 = __builtin_fmaf(t, shear_dot(r1, d), shear_dot(r1, A));
+  const float b2 = __builtin_fmaf(t, shear_dot(r2, d), shear_dot(r2, A));
+  const float b0 = 1.0f - b1 - b2;
+  const float eps = q0.w * (rmag + fabsf(t));
+  const float lo = fminf(fminf(b0, b1), b2);
+  if (!(lo >= -eps)) return 0;
+  if (lo <= eps || t - slack <= tmin) return 2;
+  if (!(t < hit.t)) return 0;
+  hit.t = t;
+  hit.b1 = b1;
+  hit.b2 = b2;
+  hit.prim = (int)f2u(q1.w);
+  return 1;
+}
+
 PT_HD float safe_inv(float d) {
   float a = fabsf(d) < 1e-20f ? (d < 0.0f ? -1e-20f : 1e-20f) : d;
   return rcp(a);
@@ -170,8 +214,6 @@ struct LocalStack {
   PT_HD StackEntry pop(int sp) const { return e[sp]; }
 };
 
-PT_HD f3 ldv(const q4& q) { return mk3(q.x, q.y, q.z); }
-
 // Closest hit (any_hit = false) or first hit (any_hit = true; hit.prim >= 0 means occluded).
 template <class Stack>
 PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, bool any_hit, Stack& stack, int stack_limit) {
@@ -180,13 +222,14 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
   rb.o = o;
   rb.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   rb.octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
-  const RayShear rs = make_shear(d);
+  const float rmag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.vmag;
 
   StackEntry cur{0u, 0x80000000u};
   int sp = 0;
   for (;;) {
     StackEntry tg;
     if (cur.bits & 0xff000000u) {
+      PT_PROF(any_hit ? PF_SH_NODE : PF_NODE);
       const uint32_t hits_imask = cur.bits;
       const int bit = 31 - __builtin_clz(hits_imask);
       cur.bits &= ~(1u << bit);
@@ -205,14 +248,23 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
       cur.bits = 0u;
     }
     while (tg.bits) {
+      PT_PROF(any_hit ? PF_SH_TRI : PF_TRI);
       const int ti = __builtin_ctz(tg.bits);
       tg.bits &= tg.bits - 1u;
-      const q4* tp = sc.tris + 3u * (tg.base + (uint32_t)ti);
-      const q4 a = tp[0], b = tp[1], c = tp[2];
-      if (intersect_triangle(rs, o, ldv(a), ldv(b), ldv(c), tmin, (int)f2u(a.w), hit) && any_hit) return hit;
+      const q4* tp = sc.tris + (uint32_t)kTriWords * (tg.base + (uint32_t)ti);
+      const q4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+      int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, tmin, hit);
+      if (res == 2) {  // rare: within rounding of an edge -- the watertight test on the original vertices decides
+        PT_PROF(PF_FALLBACK);
+        const int prim = (int)f2u(q1.w);
+        const q4* rec = reinterpret_cast<const q4*>(sc.shade + prim);
+        res = intersect_triangle(make_shear(d), o, ldv(rec[0]), ldv(rec[1]), ldv(rec[2]), tmin, prim, hit) ? 1 : 0;
+      }
+      if (res == 1 && any_hit) return hit;
     }
     if ((cur.bits & 0xff000000u) == 0u) {
       if (sp == 0) break;
+      PT_PROF(any_hit ? PF_SH_POP : PF_POP);
       cur = stack.pop(--sp);
     }
   }

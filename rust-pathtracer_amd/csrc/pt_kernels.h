@@ -73,6 +73,8 @@ void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, 
                         const int* started, int w, int h, int pattern, int min_samples, int spp, float threshold,
                         hipStream_t s);
 
+// profiling build (-DPT_PROFILE) only: section counters, (waves, lanes) pairs; returns the number of sections
+int read_profile_counters(unsigned long long* out64);
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);
 // per pixel, over its `chunks` slots: mode 0 writes the mean (sum / samples), mode 1 adds the raw sums
 void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s);

@@ -36,6 +36,10 @@ namespace pt {
 
 extern __shared__ StackEntry g_lds_stack[];
 
+#ifdef PT_PROFILE
+__device__ unsigned long long g_prof_global[64];
+#endif
+
 // Per-lane traversal stack in LDS, entry (level, lane) at [level * blockDim + lane]:
 // consecutive lanes touch consecutive 8-byte words, so pushes and pops are conflict-free.
 struct LdsStack {
@@ -276,7 +280,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
     // Small scenes: stage nodes, triangles and shading records in LDS behind the traversal
     // stacks, so the divergent 16-byte gathers of traversal and shading never leave the CU.
     u4* dst = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
-    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_tris * 3u, n_shade16 = p.scene.num_tris * 6u;
+    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_tris * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
     const u4* src_n = reinterpret_cast<const u4*>(p.scene.nodes);
     const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
     const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
@@ -288,6 +292,10 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
     sc.tris = reinterpret_cast<const q4*>(dst + n_nodes16);
     sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
   }
+#ifdef PT_PROFILE
+  if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
+  __syncthreads();
+#endif
   const ShadeParams sp = shade_params(p);
   uint32_t rays_rad = 0, rays_sh = 0;
   if (!compact && blockIdx.x == 0 && threadIdx.x == 0) p.counters[qin ^ 1] = 0u;
@@ -308,7 +316,9 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
         rc.py = sl.y;
         rc.frame = p.frame;
         for (int b = 0; b < bounces; ++b) {
+          PT_PROF(PF_BOUNCE);
           if (!(ps.flags & kAlive)) {
+            PT_PROF(PF_REGEN);
             if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the pixel's sum
               q4 acc = p.acc[pixel];
               acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z;
@@ -333,6 +343,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
             p.train[idx] = train_rec(tv);
           }
           if (sr.valid) {
+            PT_PROF(PF_SHADOW);
             rays_sh++;
             const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth);
             if (o.prim < 0) ps.sum += sr.contrib;
@@ -348,6 +359,10 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
       if (keep) q_out[slot] = pixel;
     }
   }
+#ifdef PT_PROFILE
+  __syncthreads();
+  if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
+#endif
   // ray counters: wave reduction, one 64-bit atomic pair per wave
   for (int off = 32; off > 0; off >>= 1) {
     rays_rad += __shfl_down(rays_rad, off);
@@ -484,7 +499,7 @@ void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
-  const size_t scene_bytes = (size_t)p.scene_nodes * 80u + (size_t)p.scene.num_tris * (48u + 96u);
+  const size_t scene_bytes = (size_t)p.scene_nodes * 80u + (size_t)p.scene.num_tris * (16u * kTriWords + 96u);
   const bool lds_scene = p.scene_in_lds && scene_bytes <= 24u * 1024u;
   const size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
   if (p.guiding || p.train) {
@@ -495,6 +510,18 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, con
     else k_bounce<false, false, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
   }
   PT_KCHECK();
+}
+// Profiling build only: copy out (and clear) the section counters; returns 0 in the shipped build.
+int read_profile_counters(unsigned long long* out64) {
+#ifdef PT_PROFILE
+  unsigned long long zero[64] = {0};
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof_global), sizeof(zero)) != hipSuccess) return 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_global), zero, sizeof(zero)) != hipSuccess) return 0;
+  return PF_COUNT;
+#else
+  (void)out64;
+  return 0;
+#endif
 }
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {
   k_iota<<<1024, 256, 0, s>>>(dst, n);

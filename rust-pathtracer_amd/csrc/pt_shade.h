@@ -100,6 +100,7 @@ PT_HD bool depth_and_roulette(PathState& ps, const RandCtx& rc, int max_depth) {
   const int depth = (int)ps_depth(ps);
   if (depth >= max_depth) return false;
   if (depth >= max_depth - 2) {
+    PT_PROF(PF_RR);
     const float p = max3(ps.T);
     if (next_rand(ps, rc) > p) return false;
     ps.T = ps.T * rcp(fmaxf(p, 1e-3f));
@@ -126,6 +127,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
     ps.flags &= ~kAlive;  // radiance = 0, done = 1: nothing to add
     return;
   }
+  PT_PROF(PF_SHADE);
   // optix_device.cu:404-429: geometry and material of the primitive
   const q4* rec = reinterpret_cast<const q4*>(sc.shade + hit.prim);
   const q4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
@@ -147,6 +149,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
 
   f3 radiance;
   if (Transmission > 0.0f) {
+    PT_PROF(PF_GLASS);
     // optix_device.cu:443-482: smooth dielectric, Schlick Fresnel
     const bool entering = dot(dir, Ng) < 0.0f;
     const f3 N = entering ? Ng : -Ng;
@@ -179,6 +182,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
     ps.flags &= ~kPrevValid;
     ps.prev_pdf = 0.0f;
   } else {
+    PT_PROF(PF_OPAQUE);
     // optix_device.cu:484-492
     float f0 = (IOR - 1.0f) * rcp(IOR + 1.0f);
     f0 = f0 * f0;
@@ -206,6 +210,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
       const float cosS = fmaxf(0.0f, dot(Ng, wi));
       const float cosL = fmaxf(0.0f, dot(light_n, -wi));
       if (cosS > 0.0f && cosL > 0.0f) {
+        PT_PROF(PF_NEE);
         const f3 H = normalize3(V + wi);
         const float VoH = fmaxf(dot(V, H), 0.0f);
         const float NoH = fmaxf(dot(Ng, H), 0.0f);
@@ -234,6 +239,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
     // optix_device.cu:551-561: emitted light, MIS-weighted against the previous bounce's pdf
     f3 emission = Emission;
     if ((ps.flags & kPrevValid) && (Emission.x > 0.0f || Emission.y > 0.0f || Emission.z > 0.0f)) {
+      PT_PROF(PF_EMIS_MIS);
       const f3 L = P - ps.o;
       const float dist2 = fmaxf(dot(L, L), 1e-6f);
       const float cosL = fmaxf(0.0f, dot(light_n, -dir));
@@ -245,6 +251,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
 
     const float choose = next_rand(ps, rc);
     if (choose < spec_prob) {
+      PT_PROF(PF_SPEC);
       // optix_device.cu:564-589
       const float ux = next_rand(ps, rc);
       const float uy = next_rand(ps, rc);
@@ -266,6 +273,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
       ps.prev_pdf = pdf * spec_prob;
       ps.flags |= kPrevValid;
     } else {
+      PT_PROF(PF_DIFFUSE);
       // optix_device.cu:590-658: diffuse lobe, optionally guided
       f3 newDir = mk3(0.f);
       float cosTheta = 0.f, p_guided = 0.f, p_bsdf = 0.f;

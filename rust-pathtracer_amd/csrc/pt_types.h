@@ -23,6 +23,27 @@
 #define PT_ON_DEVICE 0
 #endif
 
+// Section counters for the profiling build (-DPT_PROFILE): how many times a wave executes a
+// section and with how many active lanes.  Compiled out of the shipped library.
+#if defined(PT_PROFILE) && defined(__HIPCC__)
+__shared__ unsigned int g_prof_lds[64];
+#endif
+#if defined(PT_PROFILE) && PT_ON_DEVICE
+#define PT_PROF(k)                                                                       \
+  do {                                                                                   \
+    const unsigned long long m_ = __ballot(1);                                           \
+    if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_)) {                          \
+      atomicAdd(&g_prof_lds[2 * (k)], 1u);                                               \
+      atomicAdd(&g_prof_lds[2 * (k) + 1], (unsigned)__popcll(m_));                       \
+    }                                                                                    \
+  } while (0)
+#else
+#define PT_PROF(k) do { } while (0)
+#endif
+// profiling sections
+enum { PF_BOUNCE = 0, PF_REGEN, PF_NODE, PF_TRI, PF_SHADE, PF_GLASS, PF_OPAQUE, PF_NEE, PF_SPEC, PF_DIFFUSE,
+       PF_SH_NODE, PF_SH_TRI, PF_SHADOW, PF_POP, PF_SH_POP, PF_EMIS_MIS, PF_RR, PF_FALLBACK, PF_COUNT };
+
 namespace pt {
 
 constexpr float kPi = 3.14159265358979323846f;
@@ -180,9 +201,12 @@ struct GuideView {
 
 struct SceneView {
   const BvhNode* nodes;
-  const q4* tris;            // 3 x q4 per triangle in BVH leaf order; tris[3i].w carries the primitive index bits
+  // 4 x q4 per triangle in BVH leaf order (see TriRecord in pt_bvh.h): v0 and the rows that map
+  // (p - v0) to the barycentrics of v1, v2 and to the distance from the plane
+  const q4* tris;
   const ShadeRec* shade;     // per primitive
   uint32_t num_tris;
+  float vmag;                // largest |coordinate| of any vertex (error bound of the fast triangle test)
   // rectangle light used for next-event estimation (optix_wrapper.cpp:842-845)
   float light_pos[3], light_emit[3], light_normal[3], light_half[2];
 };

@@ -161,6 +161,7 @@ void upload_scene(State& s) {
   s.scene.tris = s.d_tris;
   s.scene.shade = s.d_shade;
   s.scene.num_tris = (uint32_t)nt;
+  s.scene.vmag = bvh.vmag;
   for (int k = 0; k < 3; ++k) {
     s.scene.light_pos[k] = hs.light_pos[k];
     s.scene.light_emit[k] = hs.light_emit[k];
@@ -779,6 +780,12 @@ int pt_get_sample_counts(int* out_counts, int* out_rounds) {
   }
   if (out_rounds) *out_rounds = s.adaptive_rounds;
   return 0;
+}
+int pt_dbg_profile_counters(uint64_t* out64) {
+  if (!g_handle) return 0;
+  HIP_CHECK(hipSetDevice(g_handle->device));
+  HIP_CHECK(hipStreamSynchronize(g_handle->stream));
+  return read_profile_counters(reinterpret_cast<unsigned long long*>(out64));
 }
 double pt_last_render_ms(void) { return g_handle ? g_handle->last_render_ms : 0.0; }
 

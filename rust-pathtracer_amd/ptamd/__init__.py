@@ -92,6 +92,7 @@ SIGNATURES = {
     "pt_get_kernel_stats": (None, [C.c_int, C.POINTER(C.c_double), _u64p, _u64p, _u64p]),
     "pt_reset_kernel_stats": (None, []),
     "pt_last_render_ms": (C.c_double, []),
+    "pt_dbg_profile_counters": (C.c_int, [C.POINTER(C.c_uint64)]),
     "pt_set_adaptive_round": (None, [C.c_int]),
     "pt_get_adaptive_round": (C.c_int, []),
     "pt_get_sample_counts": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

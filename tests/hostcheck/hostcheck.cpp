@@ -52,6 +52,7 @@ void finish_scene() {
   g_sv.tris = g_bvh.tris.data();
   g_sv.shade = g_recs.data();
   g_sv.num_tris = (uint32_t)nt;
+  g_sv.vmag = g_bvh.vmag;
   for (int k = 0; k < 3; ++k) {
     g_sv.light_pos[k] = g_hs.light_pos[k]; g_sv.light_emit[k] = g_hs.light_emit[k]; g_sv.light_normal[k] = g_hs.light_normal[k];
   }

@@ -371,9 +371,9 @@ def test_pipelines_agree_and_are_deterministic(gpu):
         L.pt_set_frame(4)
         imgs.append(gpu.render_rgb(96, 54, 32))
     assert np.array_equal(imgs[1], imgs[2])  # run-to-run bit identical
-    close = (np.abs(imgs[0] - imgs[1]) <= 1e-4 + 1e-4 * np.abs(imgs[1])).all(axis=2).mean()
-    assert close > 0.97, close
-    assert abs(imgs[0].mean() - imgs[1].mean()) / imgs[1].mean() < 0.01
+    # the kernels are compiled with products and sums fused per source expression only, so the staged
+    # and the fused pipelines round every operation alike and take the same paths
+    assert np.array_equal(imgs[0], imgs[1])
 
 
 @pytest.mark.parametrize("pipeline", [0, 1])

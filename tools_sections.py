@@ -1,0 +1,24 @@
+"""Section counters of the fused kernel (profiling build): waves and active lanes per section."""
+import os, sys
+ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ["PT_LIB_PATH"] = os.path.join(ROOT, "rust-pathtracer_amd", "libpt_hip_prof.so")
+sys.path.insert(0, os.path.join(ROOT, "rust-pathtracer_amd"))
+import ctypes as C
+import numpy as np
+import ptamd as gpu
+NAMES = ["bounce", "regen", "node", "tri", "shade", "glass", "opaque", "nee", "spec", "diffuse", "sh_node", "sh_tri",
+         "shadow", "pop", "sh_pop", "emis_mis", "rr", "fallback"]
+w, h, spp = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 64
+L = gpu.lib()
+L.pt_set_pipeline(1)
+L.pt_set_frame(0)
+L.pt_reset_ray_counts()
+gpu.render_rgb(w, h, spp)
+buf = (C.c_uint64 * 64)()
+n = L.pt_dbg_profile_counters(buf)
+rr, rs = gpu.ray_counts()
+print("sections", n, "rays", rr, rs, "ms", L.pt_last_render_ms())
+bounce_waves = buf[0]
+for k in range(n):
+    waves, lanes = buf[2 * k], buf[2 * k + 1]
+    print(f"{NAMES[k]:10s} waves {waves:14d}  per-bounce-wave {waves / max(bounce_waves, 1):7.3f}  lanes/wave {lanes / max(waves, 1):6.2f}")
