@@ -114,9 +114,10 @@ PT_EXPORT int  pt_get_mode(void);
 
 /* Integrator pipeline.  PT_PIPELINE_STAGED runs generate / extend / shade / occlude as
  * separate kernels over SoA queues in HBM; PT_PIPELINE_FUSED keeps a path in registers
- * for several bounces per launch.  Same results.  Env: PT_PIPELINE=staged|fused.  When neither
- * the call nor the variable chooses, scenes whose BVH is at most 4 MiB run fused, larger ones staged. */
-enum { PT_PIPELINE_STAGED = 0, PT_PIPELINE_FUSED = 1 };
+ * for several bounces per launch.  Same results, bit for bit.  Env: PT_PIPELINE=staged|fused.
+ * PT_PIPELINE_AUTO (the default when neither the call nor the variable chooses): scenes whose BVH is
+ * at most 4 MiB run fused; larger ones run staged until few paths are left, then finish fused. */
+enum { PT_PIPELINE_AUTO = -1, PT_PIPELINE_STAGED = 0, PT_PIPELINE_FUSED = 1 };
 PT_EXPORT void pt_set_pipeline(int pipeline);
 PT_EXPORT int  pt_get_pipeline(void);
 

@@ -51,11 +51,12 @@ struct LaunchCfg {
   hipStream_t stream;
 };
 
-// One wavefront iteration, staged: qin -> generate -> qout; extend/shade over qout; occlude.
+// One wavefront iteration, staged: qin -> generate -> qout; extend / shade / occlude over qout
+// (occlude also clears qin's counter for the next generate pass).
 void launch_generate(const RenderParams& p, int qin, const LaunchCfg& c);
 void launch_extend(const RenderParams& p, int q, const LaunchCfg& c);
 void launch_shade(const RenderParams& p, int q, const LaunchCfg& c);
-void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c);
+void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c);
 // Fused: up to `bounces` bounces per path in registers, regenerating finished samples in place.
 // compact: append survivors to queue qin^1 (the caller swaps), else process queue qin in place.
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c);

@@ -116,6 +116,35 @@ __device__ __forceinline__ void fold_squares(q4* acc2, uint32_t slot, f3 v) {
   acc2[slot] = a;
 }
 
+// Block-wide queue append for ITEMS candidates per thread: one returning atomic per block instead of
+// one per wave (the same-address atomics of a whole launch serialise in L2, ~4 ns each).
+// keep[k] tells whether the thread's k-th item survives; slot[k] receives its queue position.
+template <int ITEMS>
+__device__ __forceinline__ void block_append_slots(const bool (&keep)[ITEMS], uint32_t* counter, uint32_t (&slot)[ITEMS]) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_base;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
+  uint32_t before = 0;  // survivors of this wave in earlier items
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const unsigned long long mask = __ballot(keep[k]);
+    slot[k] = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    before += (uint32_t)__popcll(mask);
+  }
+  if (lane == 0) s_wave[wave] = before;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+    s_base = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = s_base + s_wave[wave];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) slot[k] += base;
+  __syncthreads();  // s_wave / s_base are reused by the next call
+}
+
 __device__ __forceinline__ ShadeParams shade_params(const RenderParams& p) {
   return ShadeParams{p.frame, p.max_depth, p.guiding};
 }
@@ -147,45 +176,50 @@ __device__ __forceinline__ void append_train(const RenderParams& p, const TrainV
 
 // ------------------------------------------------------------------------- generate
 __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
+  constexpr int ITEMS = 4;
   const uint32_t n = p.counters[qin];
   const uint32_t* q_in = p.queue[qin];
   uint32_t* q_out = p.queue[qin ^ 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[CNT_SHADOW] = 0u;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-    const uint32_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    uint32_t pixel = 0;
-    bool keep = false;
-    if (valid) {
-      pixel = q_in[i];
-      const u4 m = p.st_m[pixel];
-      keep = true;
-      if (!(m.w & kAlive)) {
-        int local = p.started[pixel];
-        if (m.w & kFoldPending) {  // a sample just ended: fold it into the pixel's sum
-          const q4 s = p.st_s[pixel];
-          q4 a = p.acc[pixel];
-          a.x += s.x; a.y += s.y; a.z += s.z;
-          p.acc[pixel] = a;
-          if (p.acc2) fold_squares(p.acc2, pixel, mk3(s.x, s.y, s.z));
-        }
-        const Slot sl = decode_slot(p, pixel);
-        if (local >= sl.count) {
-          keep = false;
-          // the slot may be queued again (next adaptive round): its last sample is folded only once
-          if (m.w & kFoldPending) p.st_m[pixel].w = m.w & ~kFoldPending;
-        } else {
-          const uint64_t carried = ((uint64_t)m.y << 32) | (uint64_t)m.x;
-          PathState ps;
-          generate_path(p.cam, sl.x, sl.y, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
-                        start_seed(p, sl, local, carried), ps);
-          store_state(p, pixel, ps);
-          p.started[pixel] = local + 1;
-        }
+  for (uint32_t base = blockIdx.x * (blockDim.x * ITEMS); base < n; base += gridDim.x * (blockDim.x * ITEMS)) {
+    bool keep[ITEMS];
+    uint32_t pixel[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const uint32_t i = base + (uint32_t)k * blockDim.x + threadIdx.x;
+      keep[k] = false;
+      pixel[k] = 0;
+      if (i >= n) continue;
+      pixel[k] = q_in[i];
+      const u4 m = p.st_m[pixel[k]];
+      keep[k] = true;
+      if (m.w & kAlive) continue;
+      const int local = p.started[pixel[k]];
+      if (m.w & kFoldPending) {  // a sample just ended: fold it into the slot's sum
+        const q4 s = p.st_s[pixel[k]];
+        q4 a = p.acc[pixel[k]];
+        a.x += s.x; a.y += s.y; a.z += s.z;
+        p.acc[pixel[k]] = a;
+        if (p.acc2) fold_squares(p.acc2, pixel[k], mk3(s.x, s.y, s.z));
+      }
+      const Slot sl = decode_slot(p, pixel[k]);
+      if (local >= sl.count) {
+        keep[k] = false;
+        // the slot may be queued again (next adaptive round): its last sample is folded only once
+        if (m.w & kFoldPending) p.st_m[pixel[k]].w = m.w & ~kFoldPending;
+      } else {
+        const uint64_t carried = ((uint64_t)m.y << 32) | (uint64_t)m.x;
+        PathState ps;
+        generate_path(p.cam, sl.x, sl.y, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
+                      start_seed(p, sl, local, carried), ps);
+        store_state(p, pixel[k], ps);
+        p.started[pixel[k]] = local + 1;
       }
     }
-    const uint32_t slot = wave_append_slot(keep, &p.counters[qin ^ 1]);
-    if (keep) q_out[slot] = pixel;
+    uint32_t slot[ITEMS];
+    block_append_slots<ITEMS>(keep, &p.counters[qin ^ 1], slot);
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (keep[k]) q_out[slot[k]] = pixel[k];
   }
 }
 
@@ -232,25 +266,31 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       store_state(p, pixel, ps);
     }
     if (TRAIN) append_train(p, tv);
-    const uint32_t slot = wave_append_slot(sr.valid, &p.counters[CNT_SHADOW]);
-    if (sr.valid) {
-      p.sh_o[slot] = q4{sr.o.x, sr.o.y, sr.o.z, sr.tmax};
-      p.sh_d[slot] = q4{sr.d.x, sr.d.y, sr.d.z, u2f(pixel)};
-      p.sh_c[slot] = q4{sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.f};
+    // the shadow record sits at the path's own queue position (no compaction, no atomic):
+    // tmax < 0 marks "no shadow ray", which the occlusion kernel skips
+    if (valid) {
+      if (sr.valid) {
+        p.sh_o[i] = q4{sr.o.x, sr.o.y, sr.o.z, sr.tmax};
+        p.sh_d[i] = q4{sr.d.x, sr.d.y, sr.d.z, u2f(pixel)};
+        p.sh_c[i] = q4{sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.f};
+      } else {
+        p.sh_o[i] = q4{0.f, 0.f, 0.f, -1.0f};
+      }
     }
   }
 }
 
 // -------------------------------------------------------------------------- occlude
-__global__ void __launch_bounds__(256) k_occlude(RenderParams p, int qnext_out) {
-  const uint32_t n = p.counters[CNT_SHADOW];
+__global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
+  const uint32_t n = p.counters[q];
   LdsStack st = lds_stack();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    p.ray_counters[1] += n;
-    p.counters[qnext_out] = 0u;  // the queue the next generate pass appends to
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[q ^ 1] = 0u;  // the queue the next generate pass appends to
+  uint32_t traced = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const q4 o = p.sh_o[i], d = p.sh_d[i];
+    const q4 o = p.sh_o[i];
+    if (!(o.w >= 0.0f)) continue;
+    const q4 d = p.sh_d[i];
+    traced++;
     const Hit h = trace_ray(p.scene, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 0.0f, o.w, true, st, p.stack_depth);
     if (h.prim < 0) {
       const uint32_t pixel = f2u(d.w);
@@ -260,6 +300,8 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int qnext_out) 
       p.st_s[pixel] = s;
     }
   }
+  for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
+  if ((threadIdx.x & 63u) == 0u && traced) atomicAdd(&p.ray_counters[1], (unsigned long long)traced);
 }
 
 // ---------------------------------------------------------------------------- fused
@@ -494,8 +536,8 @@ void launch_shade(const RenderParams& p, int q, const LaunchCfg& c) {
     k_shade<false, false><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
   PT_KCHECK();
 }
-void launch_occlude(const RenderParams& p, int qnext_out, const LaunchCfg& c) {
-  k_occlude<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, qnext_out);
+void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c) {
+  k_occlude<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
   PT_KCHECK();
 }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {

@@ -53,7 +53,7 @@ int mode() {
 }
 // -1 = not chosen by the caller or PT_PIPELINE: pick per scene (see effective_pipeline)
 int pipeline() {
-  if (g_pipeline < 0) g_pipeline = env_choice("PT_PIPELINE", "staged", "fused", -2);
+  if (g_pipeline == -1) g_pipeline = env_choice("PT_PIPELINE", "staged", "fused", -2);  // -2: choose per scene
   return g_pipeline;
 }
 int device_index() {
@@ -372,6 +372,7 @@ struct RenderLoop {
   RenderParams p;
   LaunchCfg cfg;
   bool fused;
+  bool tail_fused = false;
   uint64_t iter = 0;
 
   RenderLoop(State& st, const RenderParams& params) : s(st), p(params) {
@@ -385,6 +386,10 @@ struct RenderLoop {
     // HBM are latency-bound: the lean staged kernels run at twice the occupancy and win.
     const int chosen = pipeline();
     fused = chosen >= 0 ? chosen == PT_PIPELINE_FUSED : s.bvh_bytes <= (size_t)(4u << 20);
+    // Auto mode only: once few paths are left, staged iterations (one bounce, four launches) are mostly
+    // launch overhead; the fused kernel then finishes the stragglers, many bounces per launch.  Both
+    // pipelines work on the same state and give the same bits.
+    tail_fused = chosen < 0 && !fused;
   }
 
   // Clear the per-slot state of a new render.
@@ -405,13 +410,14 @@ struct RenderLoop {
     init[CNT_Q0] = n;
     HIP_CHECK(hipMemcpyAsync(s.counters, init, CNT_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
     static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
-    const int iters_per_batch = fused ? 8 : 16;
+    bool use_fused = fused;
     int qin = 0, slot = 0;
     bool have_prev = false;
     for (;;) {
+      const int iters_per_batch = use_fused ? 8 : 16;
       for (int b = 0; b < iters_per_batch; ++b, ++iter) {
         const bool timed = g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
-        if (fused) {
+        if (use_fused) {
           // compact the slot queue on the last launch of a batch only: finished slots are rare
           const int compact = (b == iters_per_batch - 1) ? 1 : 0;
           Timer t(s, PT_K_BOUNCE, timed, 0);
@@ -422,7 +428,7 @@ struct RenderLoop {
         { Timer t(s, PT_K_GENERATE, timed, 0); launch_generate(p, qin, cfg); }
         { Timer t(s, PT_K_EXTEND, timed, 0); launch_extend(p, qin ^ 1, cfg); }
         { Timer t(s, PT_K_SHADE, timed, 0); launch_shade(p, qin ^ 1, cfg); }
-        { Timer t(s, PT_K_OCCLUDE, timed, 0); launch_occlude(p, qin, cfg); }
+        { Timer t(s, PT_K_OCCLUDE, timed, 0); launch_occlude(p, qin ^ 1, cfg); }
         qin ^= 1;
       }
       HIP_CHECK(hipMemcpyAsync(s.h_counters + slot * CNT_WORDS, s.counters, CNT_WORDS * sizeof(uint32_t),
@@ -433,6 +439,7 @@ struct RenderLoop {
         HIP_CHECK(hipEventSynchronize(s.ev_slot[prev]));
         const uint32_t* c = s.h_counters + prev * CNT_WORDS;
         if (c[CNT_Q0] + c[CNT_Q1] == 0u) break;
+        if (tail_fused && c[CNT_Q0] + c[CNT_Q1] < n / 16u) use_fused = true;
       }
       have_prev = true;
       slot ^= 1;
@@ -673,8 +680,10 @@ void guiding_reset_train_write_idx(void) {
 // ======================================================================== Part 2
 void pt_set_mode(int m) { g_mode = m == PT_MODE_STRICT ? PT_MODE_STRICT : PT_MODE_CONVERGE; }
 int pt_get_mode(void) { return mode(); }
-void pt_set_pipeline(int p) { g_pipeline = p == PT_PIPELINE_STAGED ? PT_PIPELINE_STAGED : PT_PIPELINE_FUSED; }
-int pt_get_pipeline(void) { return pipeline() < 0 ? PT_PIPELINE_FUSED : pipeline(); }
+void pt_set_pipeline(int p) {
+  g_pipeline = p == PT_PIPELINE_STAGED ? PT_PIPELINE_STAGED : (p == PT_PIPELINE_FUSED ? PT_PIPELINE_FUSED : -2);
+}
+int pt_get_pipeline(void) { return pipeline() < 0 ? PT_PIPELINE_AUTO : pipeline(); }
 void pt_set_device(int d) {
   if (d != device_index()) {
     delete g_handle;

@@ -178,9 +178,17 @@ def test_trace_synthetic_scene_matches_brute_force(gpu, oracle):
         assert (prim[away] >= 0).all()
         img = gpu.render_rgb(64, 36, 8)
         assert np.isfinite(img).all() and img.mean() > 0.01
+        # a BVH this size runs staged and hands the stragglers to the fused kernel: same bits as either alone
+        imgs = []
+        for pipeline in (-1, 0, 1):
+            L.pt_set_pipeline(pipeline)
+            L.pt_set_frame(7)
+            imgs.append(gpu.render_rgb(160, 90, 16))
+        assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[1], imgs[2])
     finally:
         OL.orc_scene_set(None, 0, None, 0, None)
         L.pt_scene_cornell()
+        L.pt_set_pipeline(1)
 
 
 def test_watertight_closed_box(gpu):
