@@ -114,13 +114,16 @@ def main():
         rays_per_launch = ((rr + rs) if args.pipeline == "fused" else rr) / max(kst["launches"], 1)
         achieved_gbs = BYTES_PER_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         achieved_tflops = FLOP_PER_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
+        # HBM bytes per launch and VALU pipe occupancy come from the committed PMC passes of this same
+        # command (profiles/): counters cannot be read from inside the timed run
+        traffic, pmc = None, {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (w, h, spp) == (1920, 1080, 1024):
             try:
-                traffic = json.load(open(tpath)).get(args.pipeline, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tpath)).get(args.pipeline, {})
+                traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, pmc = None, {}
         result = {
             "metric": "Mrays/s at 1080p default scene (radiance + shadow rays)",
             "value": rays_all / elapsed / 1e6,
@@ -144,7 +147,10 @@ def main():
                          "avg_launch_ms": avg_ms, "launches": kst["launches"], "rays_per_launch": rays_per_launch,
                          "bytes_per_ray": BYTES_PER_RAY},
             "roofline_valu": {"bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved_tflops / VALU_PEAK_TFLOPS, "flop_per_ray": FLOP_PER_RAY},
+                              "frac": achieved_tflops / VALU_PEAK_TFLOPS, "flop_per_ray": FLOP_PER_RAY,
+                              "pmc_valu_pipe_busy": pmc.get("valu_pipe_busy"),
+                              "pmc_lane_utilisation": pmc.get("valu_lane_utilisation"),
+                              "pmc_valu_insts_per_ray": pmc.get("valu_insts_per_ray")},
         }
         if world == 1 and not args.no_cpu_baseline:
             import orc
