@@ -218,6 +218,44 @@ struct Emitter {
     q[3].x = (float)(n[0] * invlen); q[3].y = (float)(n[1] * invlen); q[3].z = (float)(n[2] * invlen);
   }
 
+  // A ray that leaves a surface cannot hit a triangle lying in that surface's plane; traversal drops
+  // such candidates up front.  Planes are compared through the unit normal and offset of each triangle.
+  void mark_coplanar(uint32_t node_index, uint32_t first, uint32_t count) {
+    double pl[24][4];
+    uint32_t prim[24];
+    bool ok[24];
+    for (uint32_t i = 0; i < count; ++i) {
+      prim[i] = f2u(out.tris[4 * (size_t)(first + i) + 1].w);
+      const uint32_t* t = b.idx + 3 * (size_t)prim[i];
+      double v[3][3];
+      for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < 3; ++c) v[k][c] = (double)b.verts[3 * (size_t)t[k] + c];
+      const double e1[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
+      const double e2[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
+      double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      ok[i] = len > 0.0 && std::isfinite(len);
+      if (!ok[i]) continue;
+      for (int c = 0; c < 3; ++c) pl[i][c] = n[c] / len;
+      pl[i][3] = pl[i][0] * v[0][0] + pl[i][1] * v[0][1] + pl[i][2] * v[0][2];
+    }
+    const double tol = 1e-9 * std::max(1.0, (double)out.vmag);
+    for (uint32_t i = 0; i < count; ++i) {
+      uint32_t mask = 0;
+      if (ok[i]) {
+        for (uint32_t j = 0; j < count; ++j) {
+          if (!ok[j]) continue;
+          const double dp = pl[i][0] * pl[j][0] + pl[i][1] * pl[j][1] + pl[i][2] * pl[j][2];
+          const bool same = (dp > 1.0 - 1e-12 && std::fabs(pl[i][3] - pl[j][3]) <= tol) ||
+                            (dp < -1.0 + 1e-12 && std::fabs(pl[i][3] + pl[j][3]) <= tol);
+          if (same) mask |= 1u << j;
+        }
+      }
+      out.home_node[prim[i]] = node_index;
+      out.home_mask[prim[i]] = mask;
+    }
+  }
+
   // returns the number of internal-node levels below and including this node
   int emit(uint32_t out_index, int n2) {
     // children of this node: the cost-optimal forest of up to 8 entries below n2
@@ -327,6 +365,7 @@ struct Emitter {
         tri_off += (uint32_t)cn.count;
       }
     }
+    mark_coplanar(out_index, tri_cursor, tri_off);
     tri_cursor += tri_off;
     out.nodes[out_index] = node;
 
@@ -383,6 +422,8 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   b.dp.resize(b.nodes2.size());
   b.compute_collapse(root2);
   out.tris.resize(4 * (size_t)num_tris);
+  out.home_node.assign((size_t)num_tris, 0u);
+  out.home_mask.assign((size_t)num_tris, 0u);
   out.nodes.reserve((size_t)num_tris / 2 + 16);
   out.nodes.resize(1);
   Emitter em{b, out};

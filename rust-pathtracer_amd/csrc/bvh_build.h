@@ -14,6 +14,9 @@ struct BvhBuildResult {
   std::vector<BvhNode> nodes;  // node 0 is the root
   std::vector<q4> tris;        // 4 x q4 per triangle in leaf order (traversal records, see pt_bvh.h)
   float vmag = 0.f;            // largest |coordinate| of any referenced vertex
+  // per primitive: the node whose leaf slots hold it, and the bits (offsets in that node's triangle
+  // range) of every triangle of that node lying in the same plane, itself included
+  std::vector<uint32_t> home_node, home_mask;
   int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
   int num_tris = 0;
 };

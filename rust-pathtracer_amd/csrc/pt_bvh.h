@@ -215,9 +215,19 @@ struct LocalStack {
 };
 
 // Closest hit (any_hit = false) or first hit (any_hit = true; hit.prim >= 0 means occluded).
+// origin: 1 + the primitive the ray leaves (its origin lies on that primitive's plane, pushed off towards
+// the side it travels to), or 0.  Triangles in that plane cannot be hit and are not tested; passing 0 for
+// such a ray gives the same result, only slower.
 template <class Stack>
-PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, bool any_hit, Stack& stack, int stack_limit) {
+PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, bool any_hit, Stack& stack, int stack_limit,
+                    uint32_t origin = 0u) {
   Hit hit{-1, tmax, 0.f, 0.f};
+  uint32_t home_node = 0xffffffffu, home_mask = 0u;
+  if (origin) {
+    const ShadeRec* rec = sc.shade + (origin - 1u);
+    home_node = rec->home_node;
+    home_mask = rec->home_mask;
+  }
   RayBox rb;
   rb.o = o;
   rb.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
@@ -236,12 +246,14 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
       if ((cur.bits & 0xff000000u) && sp < stack_limit) stack.push(sp++, cur);
       const uint32_t slot = (uint32_t)(bit - 24) ^ rb.octinv;
       const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
-      const NodeWords n = load_node(sc.nodes, cur.base + rel);
+      const uint32_t node_index = cur.base + rel;
+      const NodeWords n = load_node(sc.nodes, node_index);
       const uint32_t hm = intersect_children(n, rb, tmin, hit.t);
       cur.base = n.q[1].x;
       cur.bits = (hm & 0xff000000u) | (n.q[0].w >> 24);
       tg.base = n.q[1].y;
       tg.bits = hm & 0x00ffffffu;
+      if (node_index == home_node) tg.bits &= ~home_mask;
     } else {
       tg = cur;
       cur.base = 0u;

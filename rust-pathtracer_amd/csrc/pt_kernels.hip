@@ -61,6 +61,7 @@ __device__ __forceinline__ PathState load_state(const RenderParams& p, uint32_t 
   s.seed = ((uint64_t)m.y << 32) | (uint64_t)m.x;
   s.prev_pdf = u2f(m.z);
   s.flags = m.w;
+  s.origin = 0u;
   return s;
 }
 __device__ __forceinline__ void store_state(const RenderParams& p, uint32_t px, const PathState& s) {
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       if (sr.valid) {
         p.sh_o[i] = q4{sr.o.x, sr.o.y, sr.o.z, sr.tmax};
         p.sh_d[i] = q4{sr.d.x, sr.d.y, sr.d.z, u2f(pixel)};
-        p.sh_c[i] = q4{sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.f};
+        p.sh_c[i] = q4{sr.contrib.x, sr.contrib.y, sr.contrib.z, u2f(sr.origin)};
       } else {
         p.sh_o[i] = q4{0.f, 0.f, 0.f, -1.0f};
       }
@@ -290,11 +291,11 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
     const q4 o = p.sh_o[i];
     if (!(o.w >= 0.0f)) continue;
     const q4 d = p.sh_d[i];
+    const q4 c = p.sh_c[i];
     traced++;
-    const Hit h = trace_ray(p.scene, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 0.0f, o.w, true, st, p.stack_depth);
+    const Hit h = trace_ray(p.scene, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 0.0f, o.w, true, st, p.stack_depth, f2u(c.w));
     if (h.prim < 0) {
       const uint32_t pixel = f2u(d.w);
-      const q4 c = p.sh_c[i];
       q4 s = p.st_s[pixel];
       s.x += c.x; s.y += c.y; s.z += c.z;
       p.st_s[pixel] = s;
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
             local++;
           }
           rc.s = hash_sample_index(p, sl, local - 1);
-          const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth);
+          const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth, ps.origin);
           rays_rad++;
           ShadowRay sr;
           TrainVertex tv;
@@ -387,7 +388,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
           if (sr.valid) {
             PT_PROF(PF_SHADOW);
             rays_sh++;
-            const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth);
+            const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth, sr.origin);
             if (o.prim < 0) ps.sum += sr.contrib;
           }
         }

@@ -19,6 +19,9 @@ struct PathState {
   uint64_t seed;
   float prev_pdf;
   uint32_t flags;
+  // 1 + primitive the current ray leaves (see trace_ray), 0 if unknown.  Not part of the stored state:
+  // it only lets traversal skip tests that cannot succeed.
+  uint32_t origin;
 };
 constexpr uint32_t kDepthMask = 0xffu;
 constexpr uint32_t kDimShift = 8u, kDimMask = 3u << 8;
@@ -42,6 +45,7 @@ struct ShadowRay {
   float tmax;
   f3 contrib;
   bool valid;
+  uint32_t origin;  // 1 + primitive it leaves (always known: NEE needs cosS > 0)
 };
 
 struct RandCtx {
@@ -122,6 +126,8 @@ template <bool GUIDED, bool TRAIN>
 PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams& sp, const RandCtx& rc,
                      PathState& ps, const Hit& hit, ShadowRay& sr, TrainVertex& tv) {
   sr.valid = false;
+  sr.origin = 0u;
+  ps.origin = 0u;
   if (TRAIN) tv.valid = false;
   if (hit.prim < 0) {
     ps.flags &= ~kAlive;  // radiance = 0, done = 1: nothing to add
@@ -230,6 +236,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
         const f3 contrib = ld3(sc.light_emit) * f * (cosS * cosL * rcp(dist2)) * area;
         Lo = contrib * w;
         sr.valid = true;
+        sr.origin = (uint32_t)hit.prim + 1u;
         sr.o = P + Ng * 1e-3f;
         sr.d = wi;
         sr.tmax = dist - 1e-3f;
@@ -336,6 +343,9 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
     if (sr.valid) sr.contrib = Lo;
   }
 
+  // the new ray leaves this primitive's plane if it points to the side its origin was pushed to
+  if (dot(ps.d, ps.o - P) > 0.0f) ps.origin = (uint32_t)hit.prim + 1u;
+
   if (!depth_and_roulette(ps, rc, sp.max_depth)) ps.flags &= ~kAlive;
 
   // optix_device.cu:988-989: contribution = radiance * throughput (post-bounce)
@@ -357,6 +367,7 @@ PT_HD void generate_path(const CameraView& cam, int x, int y, int s, int frame, 
   ps.seed = seed;
   ps.prev_pdf = 0.0f;
   ps.flags = kAlive | kFoldPending;
+  ps.origin = 0u;
 }
 
 }  // namespace pt

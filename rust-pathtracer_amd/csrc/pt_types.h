@@ -177,8 +177,8 @@ struct alignas(16) ShadeRec {
   float v0[3]; float roughness;
   float v1[3]; float ior;
   float v2[3]; float transmission;
-  float ng[3]; float pad0;
-  float base[3]; float pad1;
+  float ng[3]; uint32_t home_node;   // BVH node whose leaf slots hold this primitive
+  float base[3]; uint32_t home_mask;  // triangles of that node in this primitive's plane (bit = offset in the node)
   float emission[3]; float pad2;
 };
 static_assert(sizeof(ShadeRec) == 96, "ShadeRec must be 96 bytes");

@@ -150,6 +150,8 @@ void upload_scene(State& s) {
     const float len = std::max(std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-20f);
     const float inv = 1.0f / len;
     for (int k = 0; k < 3; ++k) r.ng[k] = n[k] * inv;
+    r.home_node = bvh.home_node[(size_t)i];
+    r.home_mask = bvh.home_mask[(size_t)i];
     r.roughness = m.roughness;
     r.ior = m.ior;
     r.transmission = m.transmission;

@@ -27,6 +27,7 @@ std::vector<uint32_t> g_grid;
 GuideView g_gv;
 int g_guiding = 0;
 bool g_ready = false;
+int g_origin_skip = 1;  // pass the primitive a ray leaves to trace_ray (must not change any result)
 
 void finish_scene() {
   const int nt = g_hs.num_tris();
@@ -47,6 +48,7 @@ void finish_scene() {
     if (len < 1e-20f) len = 1e-20f;
     for (int k = 0; k < 3; ++k) r.ng[k] = n[k] * (1.0f / len);
     r.roughness = m.roughness; r.ior = m.ior; r.transmission = m.transmission;
+    r.home_node = g_bvh.home_node[(size_t)i]; r.home_mask = g_bvh.home_mask[(size_t)i];
   }
   g_sv.nodes = g_bvh.nodes.data();
   g_sv.tris = g_bvh.tris.data();
@@ -94,6 +96,7 @@ void hc_scene_get(float* v, uint32_t* idx, float* nrm, float* m11) {
   if (nrm) memcpy(nrm, g_hs.normals.data(), g_hs.normals.size() * 4);
   if (m11) memcpy(m11, g_hs.materials.data(), g_hs.materials.size() * sizeof(Material));
 }
+void hc_set_origin_skip(int on) { g_origin_skip = on; }
 int hc_num_vertices() { ensure(); return (int)(g_hs.vertices.size() / 3); }
 
 void hc_trace_rays(int n, const float* o, const float* d, const float* tmin, const float* tmax, int any_hit,
@@ -181,14 +184,14 @@ void hc_render(int w, int h, int sample_begin, int sample_count, int max_depth, 
           ShadeParams sp{frame, max_depth, g_guiding};
           while (ps.flags & kAlive) {
             LocalStack st;
-            Hit hit = trace_ray(g_sv, ps.o, ps.d, 0.0f, 1e16f, false, st, 64);
+            Hit hit = trace_ray(g_sv, ps.o, ps.d, 0.0f, 1e16f, false, st, 64, g_origin_skip ? ps.origin : 0u);
             a++;
             ShadowRay sr;
             TrainVertex tv;
             shade_hit<true, false>(g_sv, g_gv, sp, rc, ps, hit, sr, tv);
             if (sr.valid) {
               b++;
-              Hit o = trace_ray(g_sv, sr.o, sr.d, 0.0f, sr.tmax, true, st, 64);
+              Hit o = trace_ray(g_sv, sr.o, sr.d, 0.0f, sr.tmax, true, st, 64, g_origin_skip ? sr.origin : 0u);
               if (o.prim < 0) ps.sum += sr.contrib;
             }
           }

@@ -281,6 +281,28 @@ def test_render_logic_strict_matches_oracle(hostcheck, oracle):
     assert abs(rays[0] - orays[0]) / orays[0] < 0.02 and abs(rays[1] - orays[1]) / orays[1] < 0.02
 
 
+def test_skipping_the_origin_plane_changes_nothing(hostcheck):
+    """trace_ray may be told which primitive a ray leaves and then skips the triangles in that plane; the
+    image and the ray counts must be the same bits as without the hint (Cornell box and a scene of spheres)."""
+    for scene in ("cornell", "spheres"):
+        if scene == "cornell":
+            hostcheck.hc_scene_cornell()
+        else:
+            hostcheck.hc_scene_synthetic(7, 27, 2)
+        w, h = 40, 30
+        outs = []
+        for on in (1, 0):
+            hostcheck.hc_set_origin_skip(on)
+            out = np.zeros((h, w, 3), np.float32)
+            rays = (C.c_ulonglong * 2)()
+            hostcheck.hc_render(w, h, 0, 8, 32, 1, 0, 4, P(out), rays)
+            outs.append((out, rays[0], rays[1]))
+        hostcheck.hc_set_origin_skip(1)
+        assert np.array_equal(outs[0][0], outs[1][0])
+        assert outs[0][1:] == outs[1][1:]
+    hostcheck.hc_scene_cornell()
+
+
 # ------------------------------------------------------------------ EXR, trainer stand-in
 def test_exr_round_trip(pt, tmp_path):
     rng = np.random.default_rng(0)
