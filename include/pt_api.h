@@ -136,6 +136,14 @@ PT_EXPORT void pt_set_adaptive_round(int samples);
 PT_EXPORT int  pt_get_adaptive_round(void);
 PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
 
+/* Fused pipeline only.  on (default, env PT_DEFER_SHADOW=1): each wave queues its shadow rays in LDS
+ * and traces them 64 at a time, at full occupancy of the wave; a slot's total is the same set of
+ * terms added in a different order, so images agree with the staged pipeline to rounding (same
+ * paths).  off: shadow rays are traced where they are made and the two pipelines agree bit for bit.
+ * Adaptive renders always trace in place (the noise test needs per-sample sums). */
+PT_EXPORT void pt_set_defer_shadow(int on);
+PT_EXPORT int  pt_get_defer_shadow(void);
+
 /* Select the HIP device the next renderer is created on (default 0, or env PT_DEVICE). */
 PT_EXPORT void pt_set_device(int device);
 

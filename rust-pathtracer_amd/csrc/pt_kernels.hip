@@ -417,6 +417,169 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
   }
 }
 
+// ------------------------------------------------------------- fused, shadow rays deferred
+// Same path loop as k_bounce, but a bounce's shadow ray is not traced where it is made.  About 45 % of
+// the lanes of a wave have one per bounce, so tracing them in place runs the any-hit traversal at
+// under half occupancy of the wave.  Instead the lanes append their shadow rays to a queue the wave
+// keeps in LDS, and whenever 64 are waiting the whole wave traces them, one per lane.  An unoccluded
+// ray's contribution goes back to the lane that owns the path through an LDS accumulator and is added
+// to that slot's running sum at the end of the launch (or to the slot's total if its last sample has
+// already been folded).  A slot's total is therefore the same set of terms as in k_bounce, added in
+// a different order; per-sample sums are not preserved, so adaptive renders use k_bounce.
+constexpr uint32_t kDeferCap = 128;                       // queue entries per wave (fewer than 64 wait, up to 64 arrive)
+constexpr uint32_t kDeferFields = 12;                     // o.xyz d.xyz tmax origin contrib.xyz owner
+constexpr uint32_t kDeferWords = kDeferFields * kDeferCap + 3u * 64u;  // + per-lane accumulators
+
+template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
+__global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderParams p, int qin, int bounces, int compact) {
+  const uint32_t n = p.counters[qin];
+  const uint32_t* q_in = p.queue[qin];
+  uint32_t* q_out = p.queue[qin ^ 1];
+  LdsStack st = lds_stack();
+  SceneView sc = p.scene;
+  u4* lds_free = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
+  if (LDS_SCENE) {
+    u4* dst = lds_free;
+    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_tris * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
+    const u4* src_n = reinterpret_cast<const u4*>(p.scene.nodes);
+    const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
+    const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
+    for (uint32_t k = threadIdx.x; k < n_nodes16; k += blockDim.x) dst[k] = src_n[k];
+    for (uint32_t k = threadIdx.x; k < n_tris16; k += blockDim.x) dst[n_nodes16 + k] = src_t[k];
+    for (uint32_t k = threadIdx.x; k < n_shade16; k += blockDim.x) dst[n_nodes16 + n_tris16 + k] = src_s[k];
+    __syncthreads();
+    sc.nodes = reinterpret_cast<const BvhNode*>(dst);
+    sc.tris = reinterpret_cast<const q4*>(dst + n_nodes16);
+    sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
+    lds_free = dst + n_nodes16 + n_tris16 + n_shade16;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  float* dq = reinterpret_cast<float*>(lds_free) + (size_t)(threadIdx.x >> 6) * kDeferWords;  // this wave's queue
+  float* late = dq + kDeferFields * kDeferCap;                                                // [3][64]
+  const ShadeParams sp = shade_params(p);
+  uint32_t rays_rad = 0, rays_sh = 0;
+  if (!compact && blockIdx.x == 0 && threadIdx.x == 0) p.counters[qin ^ 1] = 0u;
+
+  // trace queue entry e on this lane; credit its owner if the light is visible
+  auto trace_deferred = [&](uint32_t e) {
+    const f3 o = mk3(dq[0 * kDeferCap + e], dq[1 * kDeferCap + e], dq[2 * kDeferCap + e]);
+    const f3 d = mk3(dq[3 * kDeferCap + e], dq[4 * kDeferCap + e], dq[5 * kDeferCap + e]);
+    const float tmax = dq[6 * kDeferCap + e];
+    const uint32_t origin = f2u(dq[7 * kDeferCap + e]);
+    rays_sh++;
+    const Hit h = trace_ray(sc, o, d, 0.0f, tmax, true, st, p.stack_depth, origin);
+    if (h.prim < 0) {
+      const uint32_t owner = f2u(dq[11 * kDeferCap + e]);
+      atomicAdd(&late[owner], dq[8 * kDeferCap + e]);
+      atomicAdd(&late[64u + owner], dq[9 * kDeferCap + e]);
+      atomicAdd(&late[128u + owner], dq[10 * kDeferCap + e]);
+    }
+  };
+
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    bool keep = false, entered = false;
+    uint32_t pixel = 0;
+    int local = 0;
+    PathState ps;
+    ps.flags = 0u;
+    Slot sl;
+    RandCtx rc;
+    if (valid) {
+      pixel = q_in[i];
+      ps = load_state(p, pixel);
+      local = p.started[pixel];
+      sl = decode_slot(p, pixel);
+      keep = (ps.flags & (kAlive | kFoldPending)) || local < sl.count;
+      entered = keep;
+      rc.px = sl.x;
+      rc.py = sl.y;
+      rc.frame = p.frame;
+    }
+    late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
+    bool active = keep;
+    // ring buffer, first in first out: a path's contributions are then added to `late` in the order
+    // its bounces made them, whatever else shares the wave, so a slot's result does not depend on
+    // which slots it is grouped with (queue order after a compaction is not reproducible)
+    uint32_t head = 0, waiting = 0;  // the same on every lane
+    for (int b = 0; b < bounces; ++b) {
+      ShadowRay sr;
+      sr.valid = false;
+      if (active && !(ps.flags & kAlive)) {
+        if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's sum
+          q4 acc = p.acc[pixel];
+          acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z;
+          p.acc[pixel] = acc;
+          ps.flags &= ~kFoldPending;
+        }
+        if (local >= sl.count) {
+          keep = false;
+          active = false;
+        } else {
+          generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
+                        start_seed(p, sl, local, ps.seed), ps);
+          local++;
+        }
+      }
+      if (active) {
+        rc.s = hash_sample_index(p, sl, local - 1);
+        const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth, ps.origin);
+        rays_rad++;
+        TrainVertex tv;
+        shade_hit<GUIDED, TRAIN>(sc, p.guide, sp, rc, ps, h, sr, tv);
+        if (TRAIN && tv.valid && p.train) {
+          uint32_t idx = atomicAdd(p.train_write_idx, 1u);
+          if (p.train_capacity) idx %= p.train_capacity;
+          p.train[idx] = train_rec(tv);
+        }
+      }
+      const unsigned long long made = __ballot(sr.valid);
+      if (sr.valid) {
+        const uint32_t e = (head + waiting + (uint32_t)__popcll(made & ((1ull << lane) - 1ull))) & (kDeferCap - 1u);
+        dq[0 * kDeferCap + e] = sr.o.x; dq[1 * kDeferCap + e] = sr.o.y; dq[2 * kDeferCap + e] = sr.o.z;
+        dq[3 * kDeferCap + e] = sr.d.x; dq[4 * kDeferCap + e] = sr.d.y; dq[5 * kDeferCap + e] = sr.d.z;
+        dq[6 * kDeferCap + e] = sr.tmax;
+        dq[7 * kDeferCap + e] = u2f(sr.origin);
+        dq[8 * kDeferCap + e] = sr.contrib.x; dq[9 * kDeferCap + e] = sr.contrib.y; dq[10 * kDeferCap + e] = sr.contrib.z;
+        dq[11 * kDeferCap + e] = u2f(lane);
+      }
+      waiting += (uint32_t)__popcll(made);
+      if (waiting >= 64u) {
+        trace_deferred((head + lane) & (kDeferCap - 1u));
+        head = (head + 64u) & (kDeferCap - 1u);
+        waiting -= 64u;
+      }
+      if (__ballot(active) == 0ull) break;
+    }
+    if (lane < waiting) trace_deferred((head + lane) & (kDeferCap - 1u));  // flush what is left, at whatever occupancy
+    if (entered) {
+      const f3 add = mk3(late[lane], late[64u + lane], late[128u + lane]);
+      if (keep) {
+        ps.sum += add;  // lands in the running sample, or in the one waiting to be folded
+      } else if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
+        q4 acc = p.acc[pixel];  // the slot's last sample is already folded
+        acc.x += add.x; acc.y += add.y; acc.z += add.z;
+        p.acc[pixel] = acc;
+      }
+      store_state(p, pixel, ps);
+      p.started[pixel] = local;
+    }
+    if (compact) {
+      const uint32_t slot = wave_append_slot(keep, &p.counters[qin ^ 1]);
+      if (keep) q_out[slot] = pixel;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    rays_rad += __shfl_down(rays_rad, off);
+    rays_sh += __shfl_down(rays_sh, off);
+  }
+  if (lane == 0u) {
+    if (rays_rad) atomicAdd(&p.ray_counters[0], (unsigned long long)rays_rad);
+    if (rays_sh) atomicAdd(&p.ray_counters[1], (unsigned long long)rays_sh);
+  }
+}
+
 // ------------------------------------------------------------------------- adaptive
 // Deterministic form of the reference's per-launch noise test (optix_device.cu:1011-1060):
 // every pixel that took part in the round computes its own noise from (sum, sum of squares, n),
@@ -544,8 +707,18 @@ void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c) {
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
   const size_t scene_bytes = (size_t)p.scene_nodes * 80u + (size_t)p.scene.num_tris * (16u * kTriWords + 96u);
   const bool lds_scene = p.scene_in_lds && scene_bytes <= 24u * 1024u;
-  const size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
-  if (p.guiding || p.train) {
+  size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
+  const bool guided = p.guiding || p.train;
+  if (p.defer_shadow && !p.acc2) {
+    lds += (size_t)(c.threads / 64) * kDeferWords * sizeof(float);
+    if (guided) {
+      if (lds_scene) k_bounce_defer<true, true, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+      else k_bounce_defer<true, true, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+    } else {
+      if (lds_scene) k_bounce_defer<false, false, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+      else k_bounce_defer<false, false, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+    }
+  } else if (guided) {
     if (lds_scene) k_bounce<true, true, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
     else k_bounce<true, true, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
   } else {

@@ -37,6 +37,7 @@ int g_timing_every = 0;
 KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
 int g_fused_bounces = 16;
+int g_defer_shadow = getenv("PT_DEFER_SHADOW") ? atoi(getenv("PT_DEFER_SHADOW")) : 1;
 int g_adaptive_round = getenv("PT_ADAPTIVE_ROUND") ? atoi(getenv("PT_ADAPTIVE_ROUND")) : -32;
 constexpr size_t kTargetSlots = 8u << 20;  // path slots worth keeping in flight (pixels x chunks)
 
@@ -351,6 +352,7 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   {
     static const int lds_scene = getenv("PT_LDS_SCENE") ? atoi(getenv("PT_LDS_SCENE")) : 1;
     p.scene_in_lds = lds_scene;
+    p.defer_shadow = g_defer_shadow;
   }
   p.st_o = s.st_o; p.st_d = s.st_d; p.st_s = s.st_s; p.st_m = s.st_m; p.acc = s.acc;
   p.started = s.started;
@@ -772,6 +774,8 @@ void pt_get_kernel_stats(int kernel, double* total_ms, uint64_t* timed_launches,
 void pt_reset_kernel_stats(void) {
   for (KernelStat& k : g_kstats) k = KernelStat();
 }
+void pt_set_defer_shadow(int on) { g_defer_shadow = on ? 1 : 0; }
+int pt_get_defer_shadow(void) { return g_defer_shadow; }
 void pt_set_adaptive_round(int samples) { g_adaptive_round = samples != 0 ? samples : -32; }
 int pt_get_adaptive_round(void) { return g_adaptive_round; }
 int pt_get_sample_counts(int* out_counts, int* out_rounds) {

@@ -93,6 +93,8 @@ SIGNATURES = {
     "pt_reset_kernel_stats": (None, []),
     "pt_last_render_ms": (C.c_double, []),
     "pt_dbg_profile_counters": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "pt_set_defer_shadow": (None, [C.c_int]),
+    "pt_get_defer_shadow": (C.c_int, []),
     "pt_set_adaptive_round": (None, [C.c_int]),
     "pt_get_adaptive_round": (C.c_int, []),
     "pt_get_sample_counts": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -180,15 +180,20 @@ def test_trace_synthetic_scene_matches_brute_force(gpu, oracle):
         assert np.isfinite(img).all() and img.mean() > 0.01
         # a BVH this size runs staged and hands the stragglers to the fused kernel: same bits as either alone
         imgs = []
+        L.pt_set_defer_shadow(0)
         for pipeline in (-1, 0, 1):
             L.pt_set_pipeline(pipeline)
             L.pt_set_frame(7)
             imgs.append(gpu.render_rgb(160, 90, 16))
         assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[1], imgs[2])
+        L.pt_set_defer_shadow(1)
+        L.pt_set_frame(7)
+        assert np.allclose(gpu.render_rgb(160, 90, 16), imgs[2], rtol=2e-5, atol=1e-7)
     finally:
         OL.orc_scene_set(None, 0, None, 0, None)
         L.pt_scene_cornell()
         L.pt_set_pipeline(1)
+        L.pt_set_defer_shadow(1)
 
 
 def test_watertight_closed_box(gpu):
@@ -374,6 +379,7 @@ def test_strict_render_matches_golden(gpu, pipeline):
 def test_pipelines_agree_and_are_deterministic(gpu):
     L = gpu.lib()
     imgs = []
+    L.pt_set_defer_shadow(0)
     for pipeline in (0, 1, 1):
         L.pt_set_pipeline(pipeline)
         L.pt_set_frame(4)
@@ -382,6 +388,23 @@ def test_pipelines_agree_and_are_deterministic(gpu):
     # the kernels are compiled with products and sums fused per source expression only, so the staged
     # and the fused pipelines round every operation alike and take the same paths
     assert np.array_equal(imgs[0], imgs[1])
+    # default fused kernel: shadow rays traced 64 at a time from a per-wave queue -- the same paths and
+    # the same terms per pixel, added in a different order
+    L.pt_set_defer_shadow(1)
+    deferred = []
+    for _ in range(2):
+        L.pt_set_frame(4)
+        L.pt_reset_ray_counts()
+        deferred.append(gpu.render_rgb(96, 54, 32))
+        rays_deferred = gpu.ray_counts()
+    assert np.array_equal(deferred[0], deferred[1])
+    assert np.allclose(deferred[0], imgs[1], rtol=2e-5, atol=1e-7)
+    L.pt_set_defer_shadow(0)
+    L.pt_set_frame(4)
+    L.pt_reset_ray_counts()
+    gpu.render_rgb(96, 54, 32)
+    assert gpu.ray_counts() == rays_deferred
+    L.pt_set_defer_shadow(1)
 
 
 @pytest.mark.parametrize("pipeline", [0, 1])
