@@ -453,6 +453,10 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
     sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
     lds_free = dst + n_nodes16 + n_tris16 + n_shade16;
   }
+#ifdef PT_PROFILE
+  if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
+  __syncthreads();
+#endif
   const uint32_t lane = threadIdx.x & 63u;
   float* dq = reinterpret_cast<float*>(lds_free) + (size_t)(threadIdx.x >> 6) * kDeferWords;  // this wave's queue
   float* late = dq + kDeferFields * kDeferCap;                                                // [3][64]
@@ -467,6 +471,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
     const float tmax = dq[6 * kDeferCap + e];
     const uint32_t origin = f2u(dq[7 * kDeferCap + e]);
     rays_sh++;
+    PT_PROF(PF_SHADOW);
     const Hit h = trace_ray(sc, o, d, 0.0f, tmax, true, st, p.stack_depth, origin);
     if (h.prim < 0) {
       const uint32_t owner = f2u(dq[11 * kDeferCap + e]);
@@ -506,7 +511,9 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
     for (int b = 0; b < bounces; ++b) {
       ShadowRay sr;
       sr.valid = false;
+      if (active) { PT_PROF(PF_BOUNCE); }
       if (active && !(ps.flags & kAlive)) {
+        PT_PROF(PF_REGEN);
         if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's sum
           q4 acc = p.acc[pixel];
           acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z;
@@ -570,6 +577,10 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
       if (keep) q_out[slot] = pixel;
     }
   }
+#ifdef PT_PROFILE
+  __syncthreads();
+  if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
+#endif
   for (int off = 32; off > 0; off >>= 1) {
     rays_rad += __shfl_down(rays_rad, off);
     rays_sh += __shfl_down(rays_sh, off);

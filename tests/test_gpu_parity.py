@@ -326,6 +326,37 @@ def test_guided_shade_step_matches_oracle(gpu, oracle):
         L.guiding_set_enabled(0)
 
 
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_guided_render_parity(gpu, oracle, pipeline):
+    """Whole guided renders (field on, seeded synthetic snapshot) against the oracle's guided render:
+    same estimator including the reference's biased guided branch, so the images agree statistically
+    and differ measurably from the unguided image."""
+    L = gpu.lib()
+    regions, lobes = synthetic_snapshot(seed=1234)
+    w, h, spp = 64, 48, 512
+    G, keep = oracle.make_guide(regions, lobes, (4, 4, 4))
+    ref, _, _, orays = oracle.render(w, h, spp, frame=1, guide=G)
+    plain = oracle.render(w, h, spp, frame=1)[0]
+    L.guiding_set_grid_res(4, 4, 4)
+    gpu.upload_snapshot(regions, lobes)
+    L.guiding_set_enabled(1)
+    L.pt_set_pipeline(pipeline)
+    try:
+        L.pt_set_frame(30)
+        L.pt_reset_ray_counts()
+        img = gpu.render_rgb(w, h, spp)
+        rr, rs = gpu.ray_counts()
+    finally:
+        L.guiding_set_enabled(0)
+        L.pt_set_pipeline(1)
+    assert abs(img.mean() - ref.mean()) / ref.mean() < 0.02
+    assert rel_rmse(img, ref) < 0.25  # two independent 512-spp estimates
+    assert abs((rr + rs) - sum(orays)) / sum(orays) < 0.02
+    # the guided estimator is not the unguided one (the reference's guided branch is biased)
+    assert abs(ref.mean() - plain.mean()) / plain.mean() > 0.03
+    assert abs(img.mean() - plain.mean()) / plain.mean() > 0.03
+
+
 def test_train_sample_ring(gpu):
     """optix_device.cu:431-441 + optix_wrapper.cpp:1270-1294; the count is clamped to the ring size."""
     L = gpu.lib()
