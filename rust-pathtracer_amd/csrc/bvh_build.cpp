@@ -3,10 +3,15 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace pt {
 namespace {
@@ -33,6 +38,7 @@ struct Node2 {
   Box box;
   int left = -1, right = -1;  // internal
   int first = 0, count = 0;   // leaf when count > 0
+  int prims = 0;              // triangles in the subtree
 };
 
 constexpr int kBins = 16;
@@ -41,9 +47,15 @@ constexpr int kMaxLeaf = 3;
 struct Builder {
   const float* verts;
   const uint32_t* idx;
-  std::vector<Box> tri_box;
-  std::vector<float> centroid;  // 3 per triangle
-  std::vector<uint32_t> order;  // triangle permutation
+  // Build-time copy of a triangle: ranges are partitioned by moving these records, so every pass
+  // over a range streams through memory instead of chasing an index list.
+  struct Prim {
+    Box box;
+    float c[3];
+    uint32_t id;
+  };
+  std::vector<Prim> prims;
+  std::vector<uint32_t> order;  // triangle permutation (prims[i].id once the binary tree is built)
   std::vector<Node2> nodes2;
   // Optimal 2-ary -> 8-ary collapse (Ylitie, Karras, Laine 2017, section 3.1): cost[n][i] is
   // the SAH cost of representing the subtree of n by a forest of at most i+1 slot entries.
@@ -64,8 +76,15 @@ struct Builder {
       c.internal = false;
       return;
     }
-    compute_collapse(nd.left);
-    compute_collapse(nd.right);
+    if (std::min(nodes2[nd.left].prims, nodes2[nd.right].prims) >= (1 << 15) && live_threads.fetch_add(1) < max_threads) {
+      std::thread worker([&] { compute_collapse(nd.left); live_threads.fetch_sub(1); });
+      compute_collapse(nd.right);
+      worker.join();
+    } else {
+      if (std::min(nodes2[nd.left].prims, nodes2[nd.right].prims) >= (1 << 15)) live_threads.fetch_sub(1);
+      compute_collapse(nd.left);
+      compute_collapse(nd.right);
+    }
     const Collapse& l = dp[(size_t)nd.left];
     const Collapse& r = dp[(size_t)nd.right];
     float dist[8];  // dist[i]: best cost of spreading the two children over i+1 slots (i >= 1)
@@ -97,96 +116,253 @@ struct Builder {
     forest(nd.right, i - k, out, count);
   }
 
-  int build2(int first, int count) {
-    Node2 n;
-    n.box.reset();
-    Box cb;
+  // nodes2 is sized up front and handed out through a counter, so subtrees can be built by
+  // different threads; the tree's shape does not depend on which thread built what.
+  std::atomic<int> next_node{0};
+  int max_threads = 1;
+  std::atomic<int> live_threads{1};
+
+  int build_root(int count) {
+    Box box, cb;
+    box.reset();
     cb.reset();
-    for (int i = first; i < first + count; ++i) {
-      n.box.grow(tri_box[order[i]]);
-      cb.grow(&centroid[3 * (size_t)order[i]]);
+    for (int i = 0; i < count; ++i) {
+      box.grow(prims[(size_t)i].box);
+      cb.grow(prims[(size_t)i].c);
     }
-    const int id = (int)nodes2.size();
-    nodes2.push_back(n);
+    return build2(0, count, box, cb);
+  }
+
+  // Ranges of a few triangles (most nodes of the tree): exact sweep SAH over the centroid order on each
+  // axis instead of bins -- cheaper than clearing and sweeping 48 bins, and never worse.
+  static constexpr int kSweepMax = 8;
+  int build_small(int id, int first, int count, const Box& box) {
+    Prim* pr = prims.data() + first;
+    float best_cost = FLT_MAX;
+    int best_axis = -1, best_split = -1;
+    uint8_t sorted[3][kSweepMax];  // positions in the range
+    Box right[kSweepMax + 1];
+    for (int axis = 0; axis < 3; ++axis) {
+      uint8_t* sa = sorted[axis];
+      for (int i = 0; i < count; ++i) sa[i] = (uint8_t)i;
+      for (int i = 1; i < count; ++i) {  // insertion sort by centroid, ties by primitive index: deterministic
+        const uint8_t t = sa[i];
+        const float c = pr[t].c[axis];
+        int j = i - 1;
+        while (j >= 0) {
+          const float cj = pr[sa[j]].c[axis];
+          if (cj < c || (cj == c && pr[sa[j]].id < pr[t].id)) break;
+          sa[j + 1] = sa[j];
+          --j;
+        }
+        sa[j + 1] = t;
+      }
+      right[count].reset();
+      for (int i = count - 1; i > 0; --i) { right[i] = right[i + 1]; right[i].grow(pr[sa[i]].box); }
+      Box left;
+      left.reset();
+      for (int i = 1; i < count; ++i) {  // split: [0,i) | [i,count)
+        left.grow(pr[sa[i - 1]].box);
+        const float cost = left.half_area() * (float)i + right[i].half_area() * (float)(count - i);
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = i; }
+      }
+    }
+    const float parent_area = box.half_area();
+    if (count <= kMaxLeaf) {
+      const float leaf_cost = (float)count * parent_area;
+      const float split_cost = 1.0f * parent_area + best_cost;
+      if (leaf_cost <= split_cost) {
+        nodes2[(size_t)id].first = first;
+        nodes2[(size_t)id].count = count;
+        return id;
+      }
+    }
+    Prim tmp[kSweepMax];
+    for (int i = 0; i < count; ++i) tmp[i] = pr[sorted[best_axis][i]];
+    for (int i = 0; i < count; ++i) pr[i] = tmp[i];
+    Box lbox, rbox, unused;
+    lbox.reset(); rbox.reset(); unused.reset();
+    for (int i = 0; i < count; ++i) (i < best_split ? lbox : rbox).grow(pr[i].box);
+    const int l = build2(first, best_split, lbox, unused);
+    const int r = build2(first + best_split, count - best_split, rbox, unused);
+    nodes2[(size_t)id].left = l;
+    nodes2[(size_t)id].right = r;
+    return id;
+  }
+
+  // box: bounds of the range's triangles; cb: bounds of their centroids (both known from the parent's bins)
+  int build2(int first, int count, const Box& box, const Box& cb) {
+    const int id = next_node.fetch_add(1);
+    Node2& self = nodes2[(size_t)id];
+    self.box = box;
+    self.prims = count;
     if (count == 1) {
-      nodes2[id].first = first;
-      nodes2[id].count = count;
+      self.first = first;
+      self.count = count;
       return id;
     }
-    // best binned SAH split over the three axes
+    if (count <= kSweepMax) return build_small(id, first, count, box);
+    // one pass bins the range on all three axes; each bin keeps its triangle and centroid bounds
+    Box bb[3][kBins], cbb[3][kBins];
+    int bc[3][kBins];
+    float lo[3], scale[3];
+    bool usable[3];
+    for (int axis = 0; axis < 3; ++axis) {
+      const float ext = cb.hi[axis] - cb.lo[axis];
+      usable[axis] = ext > 0.f;
+      lo[axis] = cb.lo[axis];
+      scale[axis] = usable[axis] ? (float)kBins / ext : 0.f;
+      for (int b = 0; b < kBins; ++b) { bb[axis][b].reset(); cbb[axis][b].reset(); bc[axis][b] = 0; }
+    }
+    for (int i = first; i < first + count; ++i) {
+      const float* c = prims[(size_t)i].c;
+      const Box& tb = prims[(size_t)i].box;
+      for (int axis = 0; axis < 3; ++axis) {
+        if (!usable[axis]) continue;
+        int b = (int)((c[axis] - lo[axis]) * scale[axis]);
+        b = std::min(std::max(b, 0), kBins - 1);
+        bb[axis][b].grow(tb);
+        cbb[axis][b].grow(c);
+        bc[axis][b]++;
+      }
+    }
     float best_cost = FLT_MAX;
     int best_axis = -1, best_bin = -1;
     for (int axis = 0; axis < 3; ++axis) {
-      const float lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
-      if (!(ext > 0.f)) continue;
-      Box bb[kBins];
-      int bc[kBins];
-      for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
-      const float scale = (float)kBins / ext;
-      for (int i = first; i < first + count; ++i) {
-        const uint32_t t = order[i];
-        int b = (int)((centroid[3 * (size_t)t + axis] - lo) * scale);
-        b = std::min(std::max(b, 0), kBins - 1);
-        bb[b].grow(tri_box[t]);
-        bc[b]++;
-      }
+      if (!usable[axis]) continue;
       float right_area[kBins];
       int right_cnt[kBins];
       Box acc;
       acc.reset();
       int c = 0;
       for (int b = kBins - 1; b > 0; --b) {
-        acc.grow(bb[b]);
-        c += bc[b];
+        acc.grow(bb[axis][b]);
+        c += bc[axis][b];
         right_area[b] = acc.half_area();
         right_cnt[b] = c;
       }
       acc.reset();
       c = 0;
       for (int b = 0; b < kBins - 1; ++b) {
-        acc.grow(bb[b]);
-        c += bc[b];
+        acc.grow(bb[axis][b]);
+        c += bc[axis][b];
         if (c == 0 || right_cnt[b + 1] == 0) continue;
         const float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
         if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
       }
     }
-    const float parent_area = nodes2[id].box.half_area();
+    const float parent_area = box.half_area();
     if (count <= kMaxLeaf) {
       // leaf cost: count triangle tests; split cost: one more node level plus the children
       const float leaf_cost = (float)count * parent_area;
       const float split_cost = best_axis < 0 ? FLT_MAX : 1.0f * parent_area + best_cost;
       if (leaf_cost <= split_cost) {
-        nodes2[id].first = first;
-        nodes2[id].count = count;
+        self.first = first;
+        self.count = count;
         return id;
       }
     }
     int mid;
-    if (best_axis < 0) {
-      mid = first + count / 2;  // all centroids coincide: split by position in the list
-    } else {
-      const float lo = cb.lo[best_axis], scale = (float)kBins / (cb.hi[best_axis] - cb.lo[best_axis]);
-      auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
-        int b = (int)((centroid[3 * (size_t)t + best_axis] - lo) * scale);
+    Box lbox, lcb, rbox, rcb;
+    lbox.reset(); lcb.reset(); rbox.reset(); rcb.reset();
+    bool have_child_bounds = false;
+    if (best_axis >= 0) {
+      const float plo = lo[best_axis], pscale = scale[best_axis];
+      auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& q) {
+        int b = (int)((q.c[best_axis] - plo) * pscale);
         b = std::min(std::max(b, 0), kBins - 1);
         return b <= best_bin;
       });
-      mid = (int)(it - order.begin());
-      if (mid == first || mid == first + count) mid = first + count / 2;
+      mid = (int)(it - prims.begin());
+      if (mid != first && mid != first + count) {
+        for (int b = 0; b < kBins; ++b) {
+          if (bc[best_axis][b] == 0) continue;
+          if (b <= best_bin) { lbox.grow(bb[best_axis][b]); lcb.grow(cbb[best_axis][b]); }
+          else { rbox.grow(bb[best_axis][b]); rcb.grow(cbb[best_axis][b]); }
+        }
+        have_child_bounds = true;
+      }
     }
-    const int l = build2(first, mid - first);
-    const int r = build2(mid, first + count - mid);
-    nodes2[id].left = l;
-    nodes2[id].right = r;
+    if (!have_child_bounds) {
+      mid = first + count / 2;  // all centroids coincide: split by position in the list
+      for (int i = first; i < first + count; ++i) {
+        Box& tbx = i < mid ? lbox : rbox;
+        Box& tcb = i < mid ? lcb : rcb;
+        tbx.grow(prims[(size_t)i].box);
+        tcb.grow(prims[(size_t)i].c);
+      }
+    }
+    const int lcount = mid - first, rcount = first + count - mid;
+    int l, r;
+    // big subtrees go to their own thread while threads are left
+    if (std::min(lcount, rcount) >= (1 << 15) && live_threads.fetch_add(1) < max_threads) {
+      // the worker gives its slot back the moment it is done, not when it is joined
+      std::thread worker([&] { l = build2(first, lcount, lbox, lcb); live_threads.fetch_sub(1); });
+      r = build2(mid, rcount, rbox, rcb);
+      worker.join();
+    } else {
+      if (std::min(lcount, rcount) >= (1 << 15)) live_threads.fetch_sub(1);
+      l = build2(first, lcount, lbox, lcb);
+      r = build2(mid, rcount, rbox, rcb);
+    }
+    nodes2[(size_t)id].left = l;
+    nodes2[(size_t)id].right = r;
     return id;
   }
 };
 
 struct Emitter {
-  const Builder& b;
+  Builder& b;
   BvhBuildResult& out;
-  uint32_t tri_cursor = 0;
+  // for the binary node that becomes an 8-wide node: 8-wide nodes strictly below it, triangles in it
+  // and below.  Known before emission, so every node's place in the arrays is fixed up front and
+  // subtrees can be emitted by different threads into the same layout a single thread would produce.
+  std::vector<uint32_t> below;
+
+  // children of the 8-wide node rooted at binary node n2: the cost-optimal forest of up to 8 entries
+  int children_of(int n2, int* child) const {
+    int nchild = 0;
+    const Node2& root = b.nodes2[n2];
+    if (root.count > 0) {
+      child[nchild++] = n2;
+      return nchild;
+    }
+    int k = 1;
+    {  // the split that compute_collapse() chose for "n2 as an internal node"
+      const auto& l = b.dp[(size_t)root.left];
+      const auto& r = b.dp[(size_t)root.right];
+      float best = FLT_MAX;
+      for (int kk = 1; kk <= 7; ++kk) {
+        const float v = l.cost[kk - 1] + r.cost[7 - kk];
+        if (v < best) { best = v; k = kk; }
+      }
+    }
+    b.forest(root.left, k - 1, child, nchild);
+    b.forest(root.right, 7 - k, child, nchild);
+    return nchild;
+  }
+
+  uint32_t count_below(int n2) {
+    int child[8];
+    const int nchild = children_of(n2, child);
+    uint32_t total = 0;
+    int big[8], nbig = 0;
+    for (int i = 0; i < nchild; ++i) {
+      if (b.nodes2[child[i]].count > 0) continue;
+      if (b.nodes2[child[i]].prims >= (1 << 16)) big[nbig++] = child[i];
+      else total += 1u + count_below(child[i]);
+    }
+    if (nbig > 0) {  // large subtrees side by side
+      uint32_t res[8];
+      std::vector<std::thread> workers;
+      for (int i = 1; i < nbig; ++i) workers.emplace_back([&, i] { res[i] = count_below(big[i]); });
+      res[0] = count_below(big[0]);
+      for (auto& w : workers) w.join();
+      for (int i = 0; i < nbig; ++i) total += 1u + res[i];
+    }
+    below[(size_t)n2] = total;
+    return total;
+  }
 
   // traversal record of a triangle (layout: TriRecord comment in pt_bvh.h), computed in double
   void write_tri(uint32_t slot_index, uint32_t prim) {
@@ -257,27 +433,11 @@ struct Emitter {
   }
 
   // returns the number of internal-node levels below and including this node
-  int emit(uint32_t out_index, int n2) {
-    // children of this node: the cost-optimal forest of up to 8 entries below n2
+  // block_start: where this node's block of internal children goes; tri_cursor: first triangle slot of
+  // this node (its leaf slots first, then its subtrees in slot order) -- depth-first order throughout
+  int emit(uint32_t out_index, int n2, uint32_t block_start, uint32_t tri_cursor) {
     int child[8];
-    int nchild = 0;
-    const Node2& root = b.nodes2[n2];
-    if (root.count > 0) {
-      child[nchild++] = n2;
-    } else {
-      int k = 1;
-      {  // the split that compute_collapse() chose for "n2 as an internal node"
-        const auto& l = b.dp[(size_t)root.left];
-        const auto& r = b.dp[(size_t)root.right];
-        float best = FLT_MAX;
-        for (int kk = 1; kk <= 7; ++kk) {
-          const float v = l.cost[kk - 1] + r.cost[7 - kk];
-          if (v < best) { best = v; k = kk; }
-        }
-      }
-      b.forest(root.left, k - 1, child, nchild);
-      b.forest(root.right, 7 - k, child, nchild);
-    }
+    const int nchild = children_of(n2, child);
     // node box and grid
     Box nb;
     nb.reset();
@@ -333,8 +493,7 @@ struct Emitter {
     int n_internal = 0;
     for (int s = 0; s < 8; ++s)
       if (child_in_slot[s] >= 0 && b.nodes2[child_in_slot[s]].count == 0) n_internal++;
-    const uint32_t child_base = (uint32_t)out.nodes.size();
-    out.nodes.resize(out.nodes.size() + (size_t)n_internal);
+    const uint32_t child_base = block_start;
     node.child_base = child_base;
     node.tri_base = tri_cursor;
     uint32_t tri_off = 0;
@@ -366,17 +525,33 @@ struct Emitter {
       }
     }
     mark_coplanar(out_index, tri_cursor, tri_off);
-    tri_cursor += tri_off;
     out.nodes[out_index] = node;
 
+    // subtrees in slot order; each one's node blocks and triangles follow those of the ones before it
     int depth_below = 0;
     uint32_t rank = 0;
+    uint32_t next_block = block_start + (uint32_t)n_internal, next_tri = tri_cursor + tri_off;
+    std::vector<std::thread> workers;
+    int worker_depth[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int s = 0; s < 8; ++s) {
       const int c = child_in_slot[s];
       if (c < 0 || b.nodes2[c].count > 0) continue;
-      depth_below = std::max(depth_below, emit(child_base + rank, c));
+      const uint32_t my_index = child_base + rank, my_block = next_block, my_tri = next_tri;
+      next_block += below[(size_t)c];
+      next_tri += (uint32_t)b.nodes2[c].prims;
+      if (b.nodes2[c].prims >= (1 << 16) && b.live_threads.fetch_add(1) < b.max_threads) {
+        workers.emplace_back([this, my_index, c, my_block, my_tri, s, &worker_depth] {
+          worker_depth[s] = emit(my_index, c, my_block, my_tri);
+          b.live_threads.fetch_sub(1);
+        });
+      } else {
+        if (b.nodes2[c].prims >= (1 << 16)) b.live_threads.fetch_sub(1);
+        depth_below = std::max(depth_below, emit(my_index, c, my_block, my_tri));
+      }
       rank++;
     }
+    for (auto& w : workers) w.join();
+    for (int s = 0; s < 8; ++s) depth_below = std::max(depth_below, worker_depth[s]);
     return 1 + depth_below;
   }
 };
@@ -399,35 +574,55 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   Builder b;
   b.verts = vertices;
   b.idx = indices;
-  b.tri_box.resize((size_t)num_tris);
-  b.centroid.resize(3 * (size_t)num_tris);
-  b.order.resize((size_t)num_tris);
-  std::iota(b.order.begin(), b.order.end(), 0u);
+  b.prims.resize((size_t)num_tris);
   for (int t = 0; t < num_tris; ++t) {
     Box bx;
     bx.reset();
     for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)t + k]);
     for (int k = 0; k < 3; ++k) out.vmag = std::max(out.vmag, std::max(std::fabs(bx.lo[k]), std::fabs(bx.hi[k])));
+    Builder::Prim& pr = b.prims[(size_t)t];
     for (int k = 0; k < 3; ++k) {
-      b.centroid[3 * (size_t)t + k] = 0.5f * (bx.lo[k] + bx.hi[k]);
+      pr.c[k] = 0.5f * (bx.lo[k] + bx.hi[k]);
       // pad so that rays grazing a flat or grid-aligned box are not lost to rounding
       const float pad = 1e-6f * std::max(std::max(std::fabs(bx.lo[k]), std::fabs(bx.hi[k])), 1e-3f);
       bx.lo[k] -= pad;
       bx.hi[k] += pad;
     }
-    b.tri_box[(size_t)t] = bx;
+    pr.box = bx;
+    pr.id = (uint32_t)t;
   }
-  b.nodes2.reserve(2 * (size_t)num_tris);
-  const int root2 = b.build2(0, num_tris);
+  b.nodes2.resize(2 * (size_t)num_tris);
+  {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const char* env = getenv("PT_BVH_THREADS");
+    b.max_threads = env ? std::max(atoi(env), 1) : (int)std::min<unsigned>(std::max(hw, 1u), 16u);
+  }
+  const bool timing = getenv("PT_BVH_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+    return std::chrono::duration<double>(b2 - a).count();
+  };
+  const auto t0 = now();
+  const int root2 = b.build_root(num_tris);
+  const auto t1 = now();
+  b.nodes2.resize((size_t)b.next_node.load());
+  b.order.resize((size_t)num_tris);
+  for (int t = 0; t < num_tris; ++t) b.order[(size_t)t] = b.prims[(size_t)t].id;
+  std::vector<Builder::Prim>().swap(b.prims);
   b.dp.resize(b.nodes2.size());
   b.compute_collapse(root2);
+  const auto t2 = now();
   out.tris.resize(4 * (size_t)num_tris);
   out.home_node.assign((size_t)num_tris, 0u);
   out.home_mask.assign((size_t)num_tris, 0u);
-  out.nodes.reserve((size_t)num_tris / 2 + 16);
-  out.nodes.resize(1);
   Emitter em{b, out};
-  out.depth = em.emit(0, root2);
+  em.below.assign(b.nodes2.size(), 0u);
+  const uint32_t nodes_below_root = em.count_below(root2);
+  out.nodes.resize(1 + (size_t)nodes_below_root);
+  out.depth = em.emit(0, root2, 1u, 0u);
+  if (timing)
+    fprintf(stderr, "bvh build: %d triangles, binary tree %.2f s (%d threads), collapse %.2f s, emit %.2f s\n", num_tris,
+            secs(t0, t1), b.max_threads, secs(t1, t2), secs(t2, now()));
   return out;
 }
 

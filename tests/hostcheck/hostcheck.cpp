@@ -97,6 +97,20 @@ void hc_scene_get(float* v, uint32_t* idx, float* nrm, float* m11) {
   if (m11) memcpy(m11, g_hs.materials.data(), g_hs.materials.size() * sizeof(Material));
 }
 void hc_set_origin_skip(int on) { g_origin_skip = on; }
+// FNV-1a over the built BVH arrays (nodes, triangle records, home masks)
+unsigned long long hc_bvh_hash() {
+  ensure();
+  unsigned long long h = 1469598103934665603ull;
+  auto feed = [&](const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+  };
+  feed(g_bvh.nodes.data(), g_bvh.nodes.size() * sizeof(BvhNode));
+  feed(g_bvh.tris.data(), g_bvh.tris.size() * sizeof(q4));
+  feed(g_bvh.home_node.data(), g_bvh.home_node.size() * 4);
+  feed(g_bvh.home_mask.data(), g_bvh.home_mask.size() * 4);
+  return h;
+}
 int hc_num_vertices() { ensure(); return (int)(g_hs.vertices.size() / 3); }
 
 void hc_trace_rays(int n, const float* o, const float* d, const float* tmin, const float* tmax, int any_hit,

@@ -281,6 +281,22 @@ def test_render_logic_strict_matches_oracle(hostcheck, oracle):
     assert abs(rays[0] - orays[0]) / orays[0] < 0.02 and abs(rays[1] - orays[1]) / orays[1] < 0.02
 
 
+def test_bvh_build_does_not_depend_on_thread_count(hostcheck):
+    """Subtrees are built, collapsed and emitted by several threads into a layout fixed up front."""
+    hostcheck.hc_bvh_hash.restype = C.c_ulonglong
+    hashes = []
+    for threads in ("1", "3", None):
+        if threads is None:
+            os.environ.pop("PT_BVH_THREADS", None)
+        else:
+            os.environ["PT_BVH_THREADS"] = threads
+        hostcheck.hc_scene_synthetic(7, 64, 3)  # 82k triangles: above the size where threads are spawned
+        hashes.append(hostcheck.hc_bvh_hash())
+    os.environ.pop("PT_BVH_THREADS", None)
+    hostcheck.hc_scene_cornell()
+    assert hashes[0] == hashes[1] == hashes[2]
+
+
 def test_skipping_the_origin_plane_changes_nothing(hostcheck):
     """trace_ray may be told which primitive a ray leaves and then skips the triangles in that plane; the
     image and the ray counts must be the same bits as without the hint (Cornell box and a scene of spheres)."""
