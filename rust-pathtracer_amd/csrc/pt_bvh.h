@@ -283,4 +283,79 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
   return hit;
 }
 
+// The same traversal as trace_ray, cut into single steps so that a kernel can interleave rays: a lane
+// whose ray has finished takes the next ray while its neighbours are still traversing theirs.
+// A ray is in one of three states: triangles of a visited node wait to be tested (wants_tri), child
+// nodes wait to be visited (wants_node), or nothing is left (done).
+struct TraceState {
+  f3 o, d;
+  RayBox rb;
+  float rmag, tmin;
+  Hit hit;
+  StackEntry cur, tg;
+  int sp;
+  uint32_t home_node, home_mask;
+
+  PT_HD void begin(const SceneView& sc, f3 o_, f3 d_, float tmin_, float tmax, uint32_t origin) {
+    o = o_;
+    d = d_;
+    tmin = tmin_;
+    hit = Hit{-1, tmax, 0.f, 0.f};
+    home_node = 0xffffffffu;
+    home_mask = 0u;
+    if (origin) {
+      const ShadeRec* rec = sc.shade + (origin - 1u);
+      home_node = rec->home_node;
+      home_mask = rec->home_mask;
+    }
+    rb.o = o;
+    rb.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    rb.octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+    rmag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.vmag;
+    cur = StackEntry{0u, 0x80000000u};
+    tg = StackEntry{0u, 0u};
+    sp = 0;
+  }
+  PT_HD bool wants_tri() const { return tg.bits != 0u; }
+  PT_HD bool wants_node() const { return tg.bits == 0u && (cur.bits != 0u || sp > 0); }  // cur.bits != 0: children left
+  PT_HD bool done() const { return tg.bits == 0u && cur.bits == 0u && sp == 0; }
+  PT_HD void finish() { tg.bits = 0u; cur.bits = 0u; sp = 0; }
+
+  // visit one child node (or take over a popped triangle group)
+  template <class Stack>
+  PT_HD void node_step(const SceneView& sc, Stack& stack, int stack_limit) {
+    if (cur.bits == 0u) cur = stack.pop(--sp);  // only entries with children left to visit are ever pushed
+    const uint32_t hits_imask = cur.bits;
+    const int bit = 31 - __builtin_clz(hits_imask);
+    cur.bits &= ~(1u << bit);
+    if ((cur.bits & 0xff000000u) && sp < stack_limit) stack.push(sp++, cur);
+    const uint32_t slot = (uint32_t)(bit - 24) ^ rb.octinv;
+    const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
+    const uint32_t node_index = cur.base + rel;
+    const NodeWords n = load_node(sc.nodes, node_index);
+    const uint32_t hm = intersect_children(n, rb, tmin, hit.t);
+    cur.base = n.q[1].x;
+    cur.bits = hm & 0xff000000u;
+    if (cur.bits) cur.bits |= n.q[0].w >> 24;
+    tg.base = n.q[1].y;
+    tg.bits = hm & 0x00ffffffu;
+    if (node_index == home_node) tg.bits &= ~home_mask;
+  }
+
+  // test one waiting triangle; returns true when an any-hit ray has found its occluder
+  PT_HD bool tri_step(const SceneView& sc, bool any_hit) {
+    const int ti = __builtin_ctz(tg.bits);
+    tg.bits &= tg.bits - 1u;
+    const q4* tp = sc.tris + (uint32_t)kTriWords * (tg.base + (uint32_t)ti);
+    const q4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+    int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, tmin, hit);
+    if (res == 2) {
+      const int prim = (int)f2u(q1.w);
+      const q4* rec = reinterpret_cast<const q4*>(sc.shade + prim);
+      res = intersect_triangle(make_shear(d), o, ldv(rec[0]), ldv(rec[1]), ldv(rec[2]), tmin, prim, hit) ? 1 : 0;
+    }
+    return res == 1 && any_hit;
+  }
+};
+
 }  // namespace pt

@@ -353,6 +353,8 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
     static const int lds_scene = getenv("PT_LDS_SCENE") ? atoi(getenv("PT_LDS_SCENE")) : 1;
     p.scene_in_lds = lds_scene;
     p.defer_shadow = g_defer_shadow;
+    static const int refill = getenv("PT_REFILL_LANES") ? atoi(getenv("PT_REFILL_LANES")) : 16;
+    p.refill_lanes = std::min(std::max(refill, 1), 64);
   }
   p.st_o = s.st_o; p.st_d = s.st_d; p.st_s = s.st_s; p.st_m = s.st_m; p.acc = s.acc;
   p.started = s.started;
