@@ -53,8 +53,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # BENCH_BACKEND=gloo rehearses the multi-rank path with several ranks on one GPU (RCCL refuses
+        # two ranks per device); the driver's runs use RCCL with one GPU per rank
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % ndev
+            dist.init_process_group(backend)
     assert world == max(args.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
