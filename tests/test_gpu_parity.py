@@ -500,6 +500,38 @@ def test_sample_chunks_sum_like_ranks(gpu):
     assert r[0, 0] == pytest.approx(max(both[0, 0, 2] / 16, 0), rel=1e-6)  # BGGR: (0,0) is blue
 
 
+def test_render_edge_cases(gpu, oracle):
+    """Tiny and odd image sizes, one sample, no samples, depth 1: same answers as the oracle's launch."""
+    L = gpu.lib()
+    L.pt_set_mode(gpu.MODE_STRICT)
+    try:
+        for pipeline in (0, 1):
+            L.pt_set_pipeline(pipeline)
+            for (w, h) in [(1, 1), (7, 3), (2, 65), (130, 1)]:
+                L.pt_set_frame(0)
+                img = gpu.render_rgb(w, h, 4)
+                ref = oracle.render(w, h, 4, frame=1, mode=oracle.STRICT)[0]
+                assert img.shape == (h, w, 3) and np.isfinite(img).all()
+                close = (np.abs(img - ref) <= 2e-3 + 2e-3 * np.abs(ref)).all(axis=2).mean()
+                assert close >= 0.85, (w, h, close)
+            L.pt_set_frame(0)
+            one = gpu.render_rgb(16, 12, 1)
+            ref1 = oracle.render(16, 12, 1, frame=1, mode=oracle.STRICT)[0]
+            assert (np.abs(one - ref1) <= 2e-3 + 2e-3 * np.abs(ref1)).all(axis=2).mean() > 0.9
+            assert not gpu.render_rgb(16, 12, 0).any()  # no samples: zeros, no division by zero
+            L.pt_set_frame(0)
+            L.pt_reset_ray_counts()
+            d1 = gpu.render_rgb(32, 24, 4, max_depth=1)
+            rr, rs = gpu.ray_counts()
+            o1, _, _, orays = oracle.render(32, 24, 4, max_depth=1, frame=1, mode=oracle.STRICT)
+            assert rr == 32 * 24 * 4 == orays[0]  # depth 1: the camera ray only (plus its shadow ray)
+            assert (np.abs(d1 - o1) <= 2e-3 + 2e-3 * np.abs(o1)).all(axis=2).mean() > 0.95
+        assert L.optix_render_rgb(8, 8, 1, 4, C.c_float(0.0), 32, None) == -1  # NULL output (optix_wrapper.cpp:980)
+    finally:
+        L.pt_set_mode(gpu.MODE_CONVERGE)
+        L.pt_set_pipeline(1)
+
+
 # ------------------------------------------------------------------ adaptive sampling
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_adaptive_sampling_matches_oracle(gpu, oracle, pipeline):
