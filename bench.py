@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=32)
     ap.add_argument("--pipeline", choices=["fused", "staged"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=48)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
