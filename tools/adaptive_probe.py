@@ -1,6 +1,6 @@
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rust-pathtracer_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-pathtracer_amd"))
 import numpy as np, ptamd as gpu, orc
 L = gpu.lib()
 w, h, spp, thr, mn, rnd = 96, 32, 256, 1.5, 32, 32

@@ -1,6 +1,6 @@
 """Adaptive render timings at 1080p (scratch tool)."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rust-pathtracer_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-pathtracer_amd"))
 import numpy as np, ptamd as gpu
 L = gpu.lib()
 gpu.render_rgb(64, 36, 1)

@@ -1,6 +1,6 @@
 """One-GPU timings of the other benchmark configurations (scratch tool): guided render, 4K Bayer + demosaic."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rust-pathtracer_amd"))
 import numpy as np, ptamd as gpu
 L = gpu.lib()

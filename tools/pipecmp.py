@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
 import numpy as np
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = C.CDLL(os.environ.get("PT_LIB_PATH", os.path.join(ROOT, "rust-pathtracer_amd", "libpt_hip.so")))
 fp = C.POINTER(C.c_float)
 L.optix_render_rgb.argtypes = [C.c_int] * 4 + [C.c_float, C.c_int, fp]

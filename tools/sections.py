@@ -1,6 +1,6 @@
 """Section counters of the fused kernel (profiling build): waves and active lanes per section."""
 import os, sys
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["PT_LIB_PATH"] = os.path.join(ROOT, "rust-pathtracer_amd", "libpt_hip_prof.so")
 sys.path.insert(0, os.path.join(ROOT, "rust-pathtracer_amd"))
 import ctypes as C
