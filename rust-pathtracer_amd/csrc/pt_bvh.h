@@ -288,18 +288,16 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
 // A ray is in one of three states: triangles of a visited node wait to be tested (wants_tri), child
 // nodes wait to be visited (wants_node), or nothing is left (done).
 struct TraceState {
-  f3 o, d;
-  RayBox rb;
-  float rmag, tmin;
+  // the ray itself (origin, direction, tmin) stays with the caller and is passed to every step
+  f3 idir;
+  uint32_t octinv;
+  float rmag;
   Hit hit;
   StackEntry cur, tg;
   int sp;
   uint32_t home_node, home_mask;
 
-  PT_HD void begin(const SceneView& sc, f3 o_, f3 d_, float tmin_, float tmax, uint32_t origin) {
-    o = o_;
-    d = d_;
-    tmin = tmin_;
+  PT_HD void begin(const SceneView& sc, f3 o, f3 d, float tmax, uint32_t origin) {
     hit = Hit{-1, tmax, 0.f, 0.f};
     home_node = 0xffffffffu;
     home_mask = 0u;
@@ -308,9 +306,8 @@ struct TraceState {
       home_node = rec->home_node;
       home_mask = rec->home_mask;
     }
-    rb.o = o;
-    rb.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    rb.octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+    idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
     rmag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.vmag;
     cur = StackEntry{0u, 0x80000000u};
     tg = StackEntry{0u, 0u};
@@ -321,18 +318,22 @@ struct TraceState {
   PT_HD bool done() const { return tg.bits == 0u && cur.bits == 0u && sp == 0; }
   PT_HD void finish() { tg.bits = 0u; cur.bits = 0u; sp = 0; }
 
-  // visit one child node (or take over a popped triangle group)
+  // visit one child node
   template <class Stack>
-  PT_HD void node_step(const SceneView& sc, Stack& stack, int stack_limit) {
+  PT_HD void node_step(const SceneView& sc, f3 o, float tmin, Stack& stack, int stack_limit) {
     if (cur.bits == 0u) cur = stack.pop(--sp);  // only entries with children left to visit are ever pushed
     const uint32_t hits_imask = cur.bits;
     const int bit = 31 - __builtin_clz(hits_imask);
     cur.bits &= ~(1u << bit);
     if ((cur.bits & 0xff000000u) && sp < stack_limit) stack.push(sp++, cur);
-    const uint32_t slot = (uint32_t)(bit - 24) ^ rb.octinv;
+    const uint32_t slot = (uint32_t)(bit - 24) ^ octinv;
     const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
     const uint32_t node_index = cur.base + rel;
     const NodeWords n = load_node(sc.nodes, node_index);
+    RayBox rb;
+    rb.o = o;
+    rb.idir = idir;
+    rb.octinv = octinv;
     const uint32_t hm = intersect_children(n, rb, tmin, hit.t);
     cur.base = n.q[1].x;
     cur.bits = hm & 0xff000000u;
@@ -343,7 +344,7 @@ struct TraceState {
   }
 
   // test one waiting triangle; returns true when an any-hit ray has found its occluder
-  PT_HD bool tri_step(const SceneView& sc, bool any_hit) {
+  PT_HD bool tri_step(const SceneView& sc, f3 o, f3 d, float tmin, bool any_hit) {
     const int ti = __builtin_ctz(tg.bits);
     tg.bits &= tg.bits - 1u;
     const q4* tp = sc.tris + (uint32_t)kTriWords * (tg.base + (uint32_t)ti);

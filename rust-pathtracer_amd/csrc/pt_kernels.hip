@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
   const uint32_t end = cursor + per < n ? cursor + per : n;
   TraceState ts;
   ts.finish();
+  f3 ro = mk3(0.f), rd = mk3(0.f);
   uint32_t idx = 0xffffffffu;  // queue position of the lane's ray, none yet
   for (;;) {
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
@@ -254,15 +255,17 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
           idx = i;
           const uint32_t pixel = queue[i];
           const q4 a = p.st_o[pixel], b = p.st_d[pixel];
-          ts.begin(p.scene, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), 0.0f, 1e16f, 0u);
+          ro = mk3(a.x, a.y, a.z);
+          rd = mk3(b.x, b.y, b.z);
+          ts.begin(p.scene, ro, rd, 1e16f, 0u);
         }
       }
       cursor += n_idle;
     } else if (n_idle == 64u) {
       break;
     }
-    if (idx != 0xffffffffu && ts.wants_node()) ts.node_step(p.scene, st, p.stack_depth);
-    if (idx != 0xffffffffu && ts.wants_tri()) ts.tri_step(p.scene, false);
+    if (idx != 0xffffffffu && ts.wants_node()) ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
+    if (idx != 0xffffffffu && ts.wants_tri()) ts.tri_step(p.scene, ro, rd, 0.0f, false);
     if (idx != 0xffffffffu && ts.done()) {
       p.hits[idx] = q4{u2f((uint32_t)ts.hit.prim), ts.hit.t, ts.hit.b1, ts.hit.b2};
       idx = 0xffffffffu;
@@ -326,6 +329,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   uint32_t traced = 0;
   TraceState ts;
   ts.finish();
+  f3 ro = mk3(0.f), rd = mk3(0.f);
   uint32_t idx = 0xffffffffu;
   for (;;) {  // same scheme as k_extend; records without a shadow ray (tmax < 0) finish at once
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
@@ -339,7 +343,9 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
             idx = i;
             const q4 d = p.sh_d[i];
             traced++;
-            ts.begin(p.scene, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 0.0f, o.w, f2u(p.sh_c[i].w));
+            ro = mk3(o.x, o.y, o.z);
+            rd = mk3(d.x, d.y, d.z);
+            ts.begin(p.scene, ro, rd, o.w, f2u(p.sh_c[i].w));
           }
         }
       }
@@ -347,8 +353,8 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
     } else if (n_idle == 64u) {
       break;
     }
-    if (idx != 0xffffffffu && ts.wants_node()) ts.node_step(p.scene, st, p.stack_depth);
-    if (idx != 0xffffffffu && ts.wants_tri() && ts.tri_step(p.scene, true)) ts.finish();
+    if (idx != 0xffffffffu && ts.wants_node()) ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
+    if (idx != 0xffffffffu && ts.wants_tri() && ts.tri_step(p.scene, ro, rd, 0.0f, true)) ts.finish();
     if (idx != 0xffffffffu && ts.done()) {
       if (ts.hit.prim < 0) {
         const uint32_t pixel = f2u(p.sh_d[idx].w);
