@@ -160,6 +160,13 @@ PT_EXPORT int  pt_get_frame(void);
  * per-pixel PCG stream, so G chunks on one GPU equal G ranks with one chunk each. */
 PT_EXPORT int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth,
                                           int frame, float* d_sum_rgb);
+/* The same with adaptive sampling: this share's samples stop per pixel by the noise test run on the
+ * share's own statistics (noise_threshold <= 0: fixed count).  ADDS the sums into d_sum_rgb (w*h*3) and
+ * the number of samples each pixel took into d_count (w*h floats), both device pointers, caller-zeroed;
+ * after the all-reduce of both, mean = sum / count. */
+PT_EXPORT int pt_render_adaptive_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth,
+                                                   int frame, float noise_threshold, int min_adaptive_samples,
+                                                   float* d_sum_rgb, float* d_count);
 /* d_rgb (w*h*3, device) -> mosaic d_raw (w*h, device); value = max(channel / divisor, 0). */
 PT_EXPORT int pt_mosaic_device(const float* d_rgb, int w, int h, int pattern, float divisor, float* d_raw);
 

@@ -81,6 +81,8 @@ int read_profile_counters(unsigned long long* out64);
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);
 // per pixel, over its `chunks` slots: mode 0 writes the mean (sum / samples), mode 1 adds the raw sums
 void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s);
+// count[p] += samples the pixel took (over its chunks)
+void launch_add_counts(const int* started, float* count, uint32_t npx, int chunks, hipStream_t s);
 // mosaic: raw[p] = max(rgb[3p + ch(p)] / divisor, 0)
 void launch_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float divisor, hipStream_t s);
 

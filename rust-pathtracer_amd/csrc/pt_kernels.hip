@@ -747,6 +747,13 @@ __global__ void k_finalize(const q4* acc, const int* started, float* out, uint32
     }
   }
 }
+__global__ void k_add_counts(const int* started, float* count, uint32_t npx, int chunks) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    int c = 0;
+    for (int k = 0; k < chunks; ++k) c += started[(size_t)k * npx + i];
+    count[i] += (float)c;
+  }
+}
 // optix_device.cu:944,990-997,1069: the mosaic value is the CFA channel of the pixel's mean, clamped at 0
 __global__ void k_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float inv_div) {
   const uint32_t npx = (uint32_t)w * (uint32_t)h;
@@ -835,6 +842,10 @@ void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, 
 }
 void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s) {
   k_finalize<<<1024, 256, 0, s>>>(acc, started, out_rgb, npx, chunks, mode);
+  PT_KCHECK();
+}
+void launch_add_counts(const int* started, float* count, uint32_t npx, int chunks, hipStream_t s) {
+  k_add_counts<<<1024, 256, 0, s>>>(started, count, npx, chunks);
   PT_KCHECK();
 }
 void launch_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float divisor, hipStream_t s) {

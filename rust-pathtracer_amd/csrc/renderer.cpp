@@ -495,9 +495,12 @@ void ensure_adaptive(State& s) {
   s.adaptive.own_noise = dev_alloc<float>(px);
 }
 
-void render_adaptive(State& s, int spp, int max_depth, int frame, bool strict, float threshold, int min_samples) {
+// sample_begin > 0: this call's samples are the global samples [sample_begin, sample_begin + spp) of every
+// pixel (one rank's share); the noise test then runs on this share's own statistics.
+void render_adaptive(State& s, int sample_begin, int spp, int max_depth, int frame, bool strict, float threshold,
+                     int min_samples) {
   ensure_adaptive(s);
-  RenderParams p = make_params(s, 0, spp, max_depth, frame, strict);
+  RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict);
   p.chunks = 1;
   p.chunk_spp = spp;
   p.acc2 = s.acc2;
@@ -543,7 +546,7 @@ int render_mean(State& s, int spp, int max_depth, float noise_threshold, int min
   g_frame++;  // optix_wrapper.cpp:983
   const bool strict = mode() == PT_MODE_STRICT;
   if (noise_threshold > 0.0f && spp > 0)
-    render_adaptive(s, spp, max_depth, g_frame, strict, noise_threshold, min_adaptive_samples);
+    render_adaptive(s, 0, spp, max_depth, g_frame, strict, noise_threshold, min_adaptive_samples);
   else
     render_core(s, 0, spp, max_depth, g_frame, strict);
   launch_finalize(s.acc, s.started, s.d_out_rgb, (uint32_t)((size_t)s.width * (size_t)s.height), s.last_chunks, 0, s.stream);
@@ -709,6 +712,22 @@ int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count
   if (!d_sum_rgb) return -1;
   render_core(s, sample_begin, sample_count, max_depth, frame, false);
   launch_finalize(s.acc, s.started, d_sum_rgb, (uint32_t)((size_t)w * (size_t)h), s.last_chunks, 1, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+int pt_render_adaptive_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth, int frame,
+                                         float noise_threshold, int min_adaptive_samples, float* d_sum_rgb,
+                                         float* d_count) {
+  State& s = ensure_handle(w, h);
+  if (!d_sum_rgb || !d_count) return -1;
+  if (noise_threshold > 0.0f && sample_count > 0)
+    render_adaptive(s, sample_begin, sample_count, max_depth, frame, false, noise_threshold, min_adaptive_samples);
+  else
+    render_core(s, sample_begin, sample_count, max_depth, frame, false);
+  const uint32_t npx = (uint32_t)((size_t)w * (size_t)h);
+  launch_finalize(s.acc, s.started, d_sum_rgb, npx, s.last_chunks, 1, s.stream);
+  launch_add_counts(s.started, d_count, npx, s.last_chunks, s.stream);
   HIP_CHECK(hipStreamSynchronize(s.stream));
   return 0;
 }

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pt_set_frame": (None, [C.c_int]),
     "pt_get_frame": (C.c_int, []),
     "pt_render_accumulate_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pt_render_adaptive_accumulate_device": (C.c_int, [C.c_int] * 6 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "pt_mosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pt_demosaic_f32": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "pt_demosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -165,6 +166,19 @@ def render_accumulate_device(sum_tensor, w, h, sample_begin, sample_count, max_d
     rc = lib().pt_render_accumulate_device(w, h, sample_begin, sample_count, max_depth, frame, sum_tensor.data_ptr())
     if rc != 0:
         raise RuntimeError(f"pt_render_accumulate_device returned {rc}")
+
+
+def render_adaptive_accumulate_device(sum_tensor, count_tensor, w, h, sample_begin, sample_count, max_depth, frame,
+                                      noise_threshold, min_adaptive_samples=32):
+    """Adaptive share of a sample-sharded render: adds sums (w*h*3) and per-pixel sample counts (w*h) into
+    two CUDA float32 tensors."""
+    for t, n in ((sum_tensor, w * h * 3), (count_tensor, w * h)):
+        assert t.is_cuda and t.dtype.is_floating_point and t.element_size() == 4 and t.numel() == n and t.is_contiguous()
+    rc = lib().pt_render_adaptive_accumulate_device(w, h, sample_begin, sample_count, max_depth, frame,
+                                                    noise_threshold, min_adaptive_samples, sum_tensor.data_ptr(),
+                                                    count_tensor.data_ptr())
+    if rc != 0:
+        raise RuntimeError(f"pt_render_adaptive_accumulate_device returned {rc}")
 
 
 def demosaic(raw, pattern=0, algo=0):

@@ -51,3 +51,17 @@ class DeviceChunkRenderer:
     def __call__(self, sums, begin, count):
         torch.cuda.synchronize(self.device)  # sums was zeroed on torch's stream
         self.pt.render_accumulate_device(sums, self.w, self.h, begin, count, self.max_depth, self.frame)
+
+
+def render_sharded_adaptive(render_share, w, h, begin, count, group=None, device=None):
+    """Adaptive variant: render_share(sum_tensor, count_tensor, begin, count) adds this rank's per-pixel RGB
+    sums (w*h*3) and sample counts (w*h); every rank stops its pixels on its own share's noise estimate.
+    Two all-reduces (sums, counts); returns (mean image [h,w,3], counts [h,w]) on every rank."""
+    sums = torch.zeros(w * h * 3, dtype=torch.float32, device=device)
+    counts = torch.zeros(w * h, dtype=torch.float32, device=device)
+    render_share(sums, counts, begin, count)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    mean = sums.view(h, w, 3) / counts.clamp(min=1.0).view(h, w, 1)
+    return mean, counts.view(h, w)

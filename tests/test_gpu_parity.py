@@ -589,6 +589,44 @@ def test_adaptive_sampling_matches_oracle(gpu, oracle, pipeline):
     assert (c_plain == 48).all() and r_plain == 0
 
 
+def test_adaptive_shares_accumulate(gpu):
+    """Sample-sharded adaptive render: two shares of 128 samples, each stopping pixels on its own noise
+    estimate, add up to sums and counts whose ratio is the image."""
+    import torch
+    from ptamd import sharded
+    L = gpu.lib()
+    w, h, per, thr = 96, 32, 128, 1.5
+    dev = torch.device("cuda:0")
+
+    def share(sums, counts, begin, count):
+        torch.cuda.synchronize()
+        gpu.render_adaptive_accumulate_device(sums, counts, w, h, begin, count, 32, 5, thr, 32)
+
+    sums = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+    counts = torch.zeros(w * h, dtype=torch.float32, device=dev)
+    share(sums, counts, 0, per)
+    c0 = counts.clone()
+    share(sums, counts, per, per)
+    c = counts.cpu().numpy().reshape(h, w)
+    c1 = c - c0.cpu().numpy().reshape(h, w)
+    assert (c[:, 0] == 64).all()  # black bars: both shares stop at their first test
+    assert c.max() == 2 * per and ((c0.cpu().numpy() % 32) == 0).all() and ((c1 % 32) == 0).all()
+    assert 0.6 < (c1 == c0.cpu().numpy().reshape(h, w)).mean() < 1.0  # same criterion, different samples
+    img = (sums.cpu().numpy().reshape(h, w, 3) / c[..., None])
+    L.pt_set_frame(4)
+    full = gpu.render_rgb(w, h, 2 * per)  # frame 5, fixed count
+    assert abs(img.mean() - full.mean()) / full.mean() < 0.05
+    # the helper (world size 1) gives the same image from one share
+    mean, cnt = sharded.render_sharded_adaptive(share, w, h, 0, per, device=dev)
+    assert torch.equal(cnt.flatten(), c0.flatten())
+    # threshold 0: fixed count, same sums as the plain accumulate entry point
+    s2 = torch.zeros_like(sums); n2 = torch.zeros_like(counts); s3 = torch.zeros_like(sums)
+    torch.cuda.synchronize()
+    gpu.render_adaptive_accumulate_device(s2, n2, w, h, 0, 48, 32, 5, 0.0, 32)
+    gpu.render_accumulate_device(s3, w, h, 0, 48, 32, 5)
+    assert torch.equal(s2, s3) and (n2 == 48).all()
+
+
 # ------------------------------------------------------------------ a16 / a17 demosaic + EXR
 @pytest.mark.parametrize("algo,name", [(0, "amaze"), (1, "bilinear")])
 def test_demosaic_bit_exact(gpu, oracle, algo, name):
