@@ -500,6 +500,44 @@ def test_sample_chunks_sum_like_ranks(gpu):
     assert r[0, 0] == pytest.approx(max(both[0, 0, 2] / 16, 0), rel=1e-6)  # BGGR: (0,0) is blue
 
 
+def test_boundary_utilities(gpu):
+    """Pinned host buffers (optix_wrapper.cpp:1132-1164), synchronize, the explicit context API
+    (927-976) and the four Bayer patterns (optix_device.cu:902-912)."""
+    L = gpu.lib()
+    w, h = 24, 16
+    nbytes = w * h * 3 * 4
+    ptr = L.optix_alloc_host(nbytes)
+    assert ptr
+    buf = (C.c_float * (w * h * 3)).from_address(ptr)
+    L.pt_set_mode(gpu.MODE_STRICT)
+    try:
+        L.pt_set_frame(0)
+        assert L.optix_render_rgb(w, h, 4, 32, C.c_float(0.0), 32, C.cast(ptr, C.POINTER(C.c_float))) == 0
+        L.optix_synchronize()
+        pinned = np.frombuffer(buf, np.float32).reshape(h, w, 3).copy()
+        L.pt_set_frame(0)
+        img = gpu.render_rgb(w, h, 4)
+        assert np.array_equal(pinned, img)
+        # pattern -> channel at (x&1, y&1): RGGB, BGGR, GRBG, GBRG
+        tiles = {0: [[0, 1], [1, 2]], 1: [[2, 1], [1, 0]], 2: [[1, 0], [2, 1]], 3: [[1, 2], [0, 1]]}
+        for pattern, tile in tiles.items():
+            L.pt_set_frame(0)
+            raw = gpu.render_bayer(w, h, 4, pattern=pattern)
+            ch = np.array([[tile[y & 1][x & 1] for x in range(w)] for y in range(h)])
+            want = np.maximum(np.take_along_axis(img, ch[..., None], 2)[..., 0], 0)
+            assert np.array_equal(raw, want), pattern
+    finally:
+        L.optix_free_host(ptr)
+        L.pt_set_mode(gpu.MODE_CONVERGE)
+    L.optix_free_host(None)  # freeing NULL is a no-op
+    ctx = L.optix_ctx_create(16, 8)
+    assert ctx
+    L.optix_ctx_set_bayer(ctx, 2)
+    L.optix_ctx_set_camera(ctx, 0.0, 3.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 60.0)
+    L.optix_ctx_destroy(ctx)
+    assert np.isfinite(gpu.render_rgb(w, h, 1)).all()  # the lazily created renderer is unaffected
+
+
 def test_render_edge_cases(gpu, oracle):
     """Tiny and odd image sizes, one sample, no samples, depth 1: same answers as the oracle's launch."""
     L = gpu.lib()
