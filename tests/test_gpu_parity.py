@@ -704,6 +704,14 @@ def test_driver_writes_exr_files(gpu, tmp_path):
     assert rgb.shape == (48, 64, 3) and dem.shape == (48, 64, 3)
     assert rgb[:, :1].max() == 0 and rgb.mean() > 0.05 and dem.mean() > 0.05
     assert abs(dem.mean() - rgb.mean()) / rgb.mean() < 0.2
+    # the reference's defaults (adaptive sampling on) with the guiding loop: train, update, snapshot, render
+    # (src/guiding.rs:222-270 through the stand-in trainer), bilinear demosaic
+    a2, b2 = str(tmp_path / "g.exr"), str(tmp_path / "g_bayer.exr")
+    out = subprocess.check_output([exe, "--width=64", "--height=48", "--spp=64", "--guiding", "--guide-grid=2x2x2",
+                                   "--demosaic=bilinear", f"--out={a2}", f"--out-bayer={b2}"], text=True, timeout=120)
+    assert "Saved" in out
+    g_rgb, g_dem = gpu.read_exr(a2), gpu.read_exr(b2)
+    assert np.isfinite(g_rgb).all() and np.isfinite(g_dem).all() and g_rgb.mean() > 0.02 and g_dem.mean() > 0.02
 
 
 # ------------------------------------------------------------------ full-size properties
