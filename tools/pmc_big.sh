@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes on the large synthetic scene, staged pipeline (scratch tool).
+# PMC passes on the large synthetic scene, staged pipeline (scratch tool). Run from the repository root.
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_big
 mkdir -p $OUT
