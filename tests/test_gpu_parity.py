@@ -196,6 +196,28 @@ def test_trace_synthetic_scene_matches_brute_force(gpu, oracle):
         L.pt_set_defer_shadow(1)
 
 
+def test_awkward_geometry_is_sound(gpu):
+    """Degenerate triangles, slivers and millimetre triangles 50 units from the origin through the GPU
+    traversal: every answer is consistent with a float64 ground truth (tests/geom_cases.py)."""
+    import geom_cases
+    L = gpu.lib()
+    V, I, centre, rng = geom_cases.awkward_scene()
+    L.pt_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
+    try:
+        o, d = geom_cases.awkward_rays(V, I, centre, rng)
+        prim, t, b1, b2 = gpu.trace_rays(o, d)
+        geom_cases.check_against_float64(V, I, o, d, prim, t, b1, b2)
+        # any-hit: occluded exactly when the closest hit lies inside the interval (away from its ends)
+        tmax = rng.uniform(0.2, 4.0, len(o)).astype(np.float32)
+        occ, _, _, _ = gpu.trace_rays(o, d, None, tmax, any_hit=True)
+        want = ((prim >= 0) & (t < tmax)).astype(np.int32)
+        clear = np.abs(t - tmax) > 1e-3
+        assert (occ[clear] >= want[clear]).all()  # an occluder behind the closest hit may also be found
+        assert (occ[(prim < 0)] == 0).all()
+    finally:
+        L.pt_scene_cornell()
+
+
 def test_watertight_closed_box(gpu):
     """No ray leaving an interior point away from the open front escapes (shared diagonals / edges)."""
     rng = np.random.default_rng(3)

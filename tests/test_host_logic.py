@@ -147,6 +147,28 @@ def test_traversal_logic_matches_brute_force_soup(hostcheck, oracle):
         hostcheck.hc_scene_cornell()
 
 
+def test_awkward_geometry_matches_brute_force(hostcheck, oracle):
+    """Degenerate triangles, slivers, tiny triangles far from the origin: the fast triangle test's error
+    band has to hand every doubtful case to the watertight test, so the answers stay sound against a float64
+    ground truth (and so do the oracle's)."""
+    import geom_cases
+    V, I, centre, rng = geom_cases.awkward_scene()
+    hostcheck.hc_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
+    oracle.lib().orc_scene_set(P(V), len(V), P(I, C.c_uint32), len(I), None)
+    try:
+        o, d = geom_cases.awkward_rays(V, I, centre, rng)
+        prim, t, b1, b2 = _hc_trace(hostcheck, o, d)
+        definite_miss, strict_miss, t_first, rows = geom_cases.check_against_float64(V, I, o, d, prim, t, b1, b2)
+        # the oracle's brute-force loop passes the same checks on the same rays
+        op, ot = _orc_trace(oracle, o, d)
+        oh = op >= 0
+        assert not strict_miss[rows[oh], op[oh]].any() and not np.isfinite(t_first[~oh]).any()
+        assert (prim != op).mean() < 0.08  # they differ only inside the margins
+    finally:
+        oracle.lib().orc_scene_set(None, 0, None, 0, None)
+        hostcheck.hc_scene_cornell()
+
+
 def test_watertight_no_leak_through_shared_edges(hostcheck):
     """Rays aimed exactly at quad diagonals, edges and corners of the closed part of the box
     must hit something (the two triangles of a quad share their diagonal)."""
