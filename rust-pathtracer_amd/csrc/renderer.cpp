@@ -247,7 +247,8 @@ State* make_state(int W, int H) {
   const size_t px = (size_t)W * (size_t)H;
   // A pixel's sample range may be rendered as several chunks side by side (one slot each);
   // state is sized for the most chunks a render of this resolution will use.
-  s->max_chunks = (int)std::max<size_t>(1, std::min<size_t>(16, kTargetSlots / std::max<size_t>(px, 1)));
+  static const size_t target_slots = getenv("PT_TARGET_SLOTS") ? (size_t)atoll(getenv("PT_TARGET_SLOTS")) : kTargetSlots;
+  s->max_chunks = (int)std::max<size_t>(1, std::min<size_t>(16, target_slots / std::max<size_t>(px, 1)));
   const size_t slots = px * (size_t)s->max_chunks;
   s->st_o = dev_alloc<q4>(slots); s->st_d = dev_alloc<q4>(slots); s->st_s = dev_alloc<q4>(slots);
   s->st_m = dev_alloc<u4>(slots); s->acc = dev_alloc<q4>(slots); s->hits = dev_alloc<q4>(slots);
