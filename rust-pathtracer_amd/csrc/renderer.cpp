@@ -203,8 +203,9 @@ void upload_guide(State& s) {
   for (uint32_t r = 0; r < nr; ++r) {
     int lo[3], hi[3];
     for (int k = 0; k < 3; ++k) {
-      lo[k] = (int)std::floor((hreg[r].bmin[k] - bmin[k]) / cell[k]);
-      hi[k] = (int)std::floor((hreg[r].bmax[k] - bmin[k]) / cell[k]);
+      // a field that is flat along an axis has zero-size cells there: everything falls into cell 0
+      lo[k] = cell[k] > 0.f ? (int)std::floor((hreg[r].bmin[k] - bmin[k]) / cell[k]) : 0;
+      hi[k] = cell[k] > 0.f ? (int)std::floor((hreg[r].bmax[k] - bmin[k]) / cell[k]) : 0;
       lo[k] = std::max(0, std::min(res[k] - 1, lo[k]));
       hi[k] = std::max(0, std::min(res[k] - 1, hi[k]));
     }
