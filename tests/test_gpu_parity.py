@@ -736,6 +736,37 @@ def test_driver_writes_exr_files(gpu, tmp_path):
     assert np.isfinite(g_rgb).all() and np.isfinite(g_dem).all() and g_rgb.mean() > 0.02 and g_dem.mean() > 0.02
 
 
+def test_layout_matches_reference_render_at_its_own_size(gpu):
+    """The reference's committed pt.png (1920x1440, region means in tests/golden/ptpng_regions.json) against
+    a GPU render of the same size: black side bars, the coloured walls on the same sides with the same
+    dominant channel, a neutral back wall, the light brighter than everything else."""
+    import json
+    meta = json.load(open(os.path.join(GOLD, "ptpng_regions.json")))
+    reg = meta["regions"]
+    w, h = meta["size"]
+    L = gpu.lib()
+    L.pt_set_frame(0)
+    rgb = gpu.render_rgb(w, h, 64)
+
+    def mean(name):
+        x0, x1, y0, y1 = reg[name]["frac"]
+        return rgb[int(y0 * h):int(y1 * h), int(x0 * w):int(x1 * w)].mean(axis=(0, 1))
+
+    for name in ("left_bar", "right_bar"):
+        assert reg[name]["mean_rgb8"] == [0.0, 0.0, 0.0] and np.all(mean(name) == 0.0)
+    lw, rw, bw, light = mean("left_wall"), mean("right_wall"), mean("back_wall"), mean("light")
+    assert np.argmax(lw) == int(np.argmax(reg["left_wall"]["mean_rgb8"]))
+    assert np.argmax(rw) == int(np.argmax(reg["right_wall"]["mean_rgb8"]))
+    assert np.argmin(lw) == int(np.argmin(reg["left_wall"]["mean_rgb8"]))
+    assert np.argmin(rw) == int(np.argmin(reg["right_wall"]["mean_rgb8"]))
+    assert bw.max() / bw.min() < 1.3 < min(lw.max() / lw.min(), rw.max() / rw.min())
+    assert light.min() > 3 * bw.max()
+    # brightness order of the regions is the one of the reference image
+    order_ref = sorted(("left_wall", "right_wall", "back_wall", "light"), key=lambda k: sum(reg[k]["mean_rgb8"]))
+    order_gpu = sorted(("left_wall", "right_wall", "back_wall", "light"), key=lambda k: float(mean(k).sum()))
+    assert order_ref[-1] == order_gpu[-1] == "light"
+
+
 # ------------------------------------------------------------------ full-size properties
 def test_full_size_1080p_properties(gpu):
     """BASELINE's 1080p configuration at reduced spp: properties that do not need a CPU render."""
