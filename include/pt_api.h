@@ -76,7 +76,9 @@ PT_EXPORT void guiding_upload_snapshot(const struct pgl_region* regions, uint32_
 PT_EXPORT void guiding_set_enabled(int enabled);
 PT_EXPORT void guiding_set_train_buffer_size(uint32_t n);
 /* Returns a pointer into library-owned storage valid until the next call.  Unlike
- * optix_wrapper.cpp:1279-1285 the count is clamped to the ring capacity. */
+ * optix_wrapper.cpp:1279-1285 the count is clamped to the ring capacity, and the records are the
+ * ring slots that were written: vertices are stored at hashed slots instead of being appended
+ * through one atomic counter, so the ring holds a random subset of the render's non-delta vertices. */
 PT_EXPORT void guiding_map_train_samples(const TrainSample** samples, uint32_t* count);
 PT_EXPORT void guiding_reset_train_write_idx(void);
 PT_EXPORT void guiding_set_grid_res(int x, int y, int z);

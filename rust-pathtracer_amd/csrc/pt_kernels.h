@@ -48,6 +48,9 @@ struct RenderParams {
   uint32_t train_capacity;
 };
 
+// is_delta value of a training-ring slot that no vertex has been written to (the ring is cleared to 0xff bytes)
+constexpr uint32_t kTrainEmpty = 0xffffffffu;
+
 struct LaunchCfg {
   int blocks, threads;
   hipStream_t stream;

@@ -158,21 +158,25 @@ __device__ __forceinline__ TrainRec train_rec(const TrainVertex& tv) {
   r.is_delta = 0u;
   return r;
 }
-// One atomic per wave for all lanes that captured a training vertex (optix_device.cu:438-440).
-__device__ __forceinline__ void append_train(const RenderParams& p, const TrainVertex& tv) {
-  if (!p.train) return;
-  const bool want = tv.valid;
-  const unsigned long long mask = __ballot(want);
-  if (!mask) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t base = 0;
-  if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(p.train_write_idx, (uint32_t)__popcll(mask));
-  base = __shfl(base, __builtin_ctzll(mask));
-  if (want) {
-    uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (p.train_capacity) idx %= p.train_capacity;
-    p.train[idx] = train_rec(tv);
-  }
+// Training capture (optix_device.cu:431-441).  The reference appends every non-delta vertex to a ring
+// through one atomic counter; a 1080p render makes thousands of times more vertices than the ring holds,
+// and that counter then serialises the whole render (a returning same-address atomic per wave and bounce
+// made the fused kernel 2.7x slower).  Here a vertex goes to the ring slot its own random state hashes
+// to -- what survives is a uniform random subset of the render's vertices instead of whichever were
+// appended last -- and the number of vertices is only counted (per lane, summed when the kernel ends).
+// Never-written slots keep the marker the ring is cleared to (is_delta == kTrainEmpty) and are dropped
+// when the host maps the ring.
+__device__ __forceinline__ void capture_train(const RenderParams& p, const TrainVertex& tv, uint64_t seed, uint32_t slot,
+                                              uint32_t& captured) {
+  if (!p.train || !tv.valid) return;
+  captured++;
+  if (!p.train_capacity) return;
+  const uint32_t key = hash_u32((uint32_t)seed ^ (uint32_t)(seed >> 32) ^ (slot * 0x9E3779B1u));
+  p.train[key % p.train_capacity] = train_rec(tv);
+}
+__device__ __forceinline__ void flush_train_count(const RenderParams& p, uint32_t captured) {
+  for (int off = 32; off > 0; off >>= 1) captured += __shfl_down(captured, off);
+  if ((threadIdx.x & 63u) == 0u && captured && p.train_write_idx) atomicAdd(p.train_write_idx, captured);
 }
 
 // ------------------------------------------------------------------------- generate
@@ -279,6 +283,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
   const uint32_t n = p.counters[q];
   const uint32_t* queue = p.queue[q];
   const ShadeParams sp = shade_params(p);
+  uint32_t captured = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const bool valid = i < n;
@@ -287,6 +292,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
     TrainVertex tv;
     tv.valid = false;
     uint32_t pixel = 0;
+    uint64_t seed_after = 0;
     if (valid) {
       pixel = queue[i];
       PathState ps = load_state(p, pixel);
@@ -299,9 +305,10 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       rc.frame = p.frame;
       rc.s = ps_dim(ps) < 2u ? hash_sample_index(p, sl, p.started[pixel] - 1) : 0;
       shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
+      seed_after = ps.seed;
       store_state(p, pixel, ps);
     }
-    if (TRAIN) append_train(p, tv);
+    if (TRAIN && valid) capture_train(p, tv, seed_after, pixel, captured);
     // the shadow record sits at the path's own queue position (no compaction, no atomic):
     // tmax < 0 marks "no shadow ray", which the occlusion kernel skips
     if (valid) {
@@ -314,6 +321,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       }
     }
   }
+  if (TRAIN) flush_train_count(p, captured);
 }
 
 // -------------------------------------------------------------------------- occlude
@@ -405,7 +413,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
   __syncthreads();
 #endif
   const ShadeParams sp = shade_params(p);
-  uint32_t rays_rad = 0, rays_sh = 0;
+  uint32_t rays_rad = 0, rays_sh = 0, captured = 0;
   if (!compact && blockIdx.x == 0 && threadIdx.x == 0) p.counters[qin ^ 1] = 0u;
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
@@ -445,11 +453,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
           ShadowRay sr;
           TrainVertex tv;
           shade_hit<GUIDED, TRAIN>(sc, p.guide, sp, rc, ps, h, sr, tv);
-          if (TRAIN && tv.valid && p.train) {
-            uint32_t idx = atomicAdd(p.train_write_idx, 1u);
-            if (p.train_capacity) idx %= p.train_capacity;
-            p.train[idx] = train_rec(tv);
-          }
+          if (TRAIN) capture_train(p, tv, ps.seed, pixel, captured);
           if (sr.valid) {
             PT_PROF(PF_SHADOW);
             rays_sh++;
@@ -471,6 +475,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
   __syncthreads();
   if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
 #endif
+  if (TRAIN) flush_train_count(p, captured);
   // ray counters: wave reduction, one 64-bit atomic pair per wave
   for (int off = 32; off > 0; off >>= 1) {
     rays_rad += __shfl_down(rays_rad, off);
@@ -526,7 +531,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
   float* dq = reinterpret_cast<float*>(lds_free) + (size_t)(threadIdx.x >> 6) * kDeferWords;  // this wave's queue
   float* late = dq + kDeferFields * kDeferCap;                                                // [3][64]
   const ShadeParams sp = shade_params(p);
-  uint32_t rays_rad = 0, rays_sh = 0;
+  uint32_t rays_rad = 0, rays_sh = 0, captured = 0;
   if (!compact && blockIdx.x == 0 && threadIdx.x == 0) p.counters[qin ^ 1] = 0u;
 
   // trace queue entry e on this lane; credit its owner if the light is visible
@@ -600,11 +605,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
         rays_rad++;
         TrainVertex tv;
         shade_hit<GUIDED, TRAIN>(sc, p.guide, sp, rc, ps, h, sr, tv);
-        if (TRAIN && tv.valid && p.train) {
-          uint32_t idx = atomicAdd(p.train_write_idx, 1u);
-          if (p.train_capacity) idx %= p.train_capacity;
-          p.train[idx] = train_rec(tv);
-        }
+        if (TRAIN) capture_train(p, tv, ps.seed, pixel, captured);
       }
       const unsigned long long made = __ballot(sr.valid);
       if (sr.valid) {
@@ -646,6 +647,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
   __syncthreads();
   if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
 #endif
+  if (TRAIN) flush_train_count(p, captured);
   for (int off = 32; off > 0; off >>= 1) {
     rays_rad += __shfl_down(rays_rad, off);
     rays_sh += __shfl_down(rays_sh, off);

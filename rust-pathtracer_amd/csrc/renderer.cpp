@@ -271,6 +271,7 @@ State* make_state(int W, int H) {
     s->d_train = dev_alloc<TrainRec>(g_train_capacity);
     s->d_train_idx = dev_alloc<uint32_t>(1);
     HIP_CHECK(hipMemset(s->d_train_idx, 0, sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(s->d_train, 0xff, sizeof(TrainRec) * (size_t)g_train_capacity));  // every slot: never written
   }
   if (!g_snap_regions.empty()) upload_guide(*s);
   return s;
@@ -679,13 +680,20 @@ void guiding_map_train_samples(const TrainSample** samples, uint32_t* count) {
   HIP_CHECK(hipMemcpy(host.data(), st.d_train, sizeof(TrainSample) * (size_t)st.train_capacity, hipMemcpyDeviceToHost));
   uint32_t n = 0;
   HIP_CHECK(hipMemcpy(&n, st.d_train_idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  // vertices land in hashed slots (see capture_train): keep the slots that were written, in ring order
+  size_t kept = 0;
+  for (size_t i = 0; i < host.size(); ++i)
+    if (host[i].is_delta != kTrainEmpty) host[kept++] = host[i];
   if (samples) *samples = host.data();
-  if (count) *count = std::min(n, st.train_capacity);  // the ring wraps; never report more than it holds
+  // never report more than were captured or than the ring holds (the reference reports the raw counter)
+  if (count) *count = (uint32_t)std::min<size_t>(kept, std::min(n, st.train_capacity));
 }
 void guiding_reset_train_write_idx(void) {
   if (!g_handle || !g_handle->d_train_idx) return;
   HIP_CHECK(hipSetDevice(g_handle->device));
   HIP_CHECK(hipMemset(g_handle->d_train_idx, 0, sizeof(uint32_t)));
+  if (g_handle->d_train)
+    HIP_CHECK(hipMemset(g_handle->d_train, 0xff, sizeof(TrainRec) * (size_t)g_handle->train_capacity));
 }
 
 // ======================================================================== Part 2
