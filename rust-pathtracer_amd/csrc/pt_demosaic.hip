@@ -22,12 +22,12 @@ enum { CFA_R = 0, CFA_G = 1, CFA_B = 2 };
 // src/main.rs:157-173
 __device__ __forceinline__ int cfa_at(int x, int y, int pattern) {
   const int p = pattern < 0 ? 0 : (pattern > 3 ? 3 : pattern);
-  const int my = y & 1, mx = x & 1;
-  // rows of the four 2x2 tables, 2 bits per entry: R=0 G=1 B=2
+  // the four 2x2 tables, 2 bits per entry (R=0 G=1 B=2), one byte per pattern:
   // p0 RGGB: [R G; G B]  p1 BGGR: [B G; G R]  p2 GRBG: [G R; B G]  p3 GBRG: [G B; R G]
-  const unsigned tables[4] = {0x0u | (1u << 2) | (1u << 4) | (2u << 6), 2u | (1u << 2) | (1u << 4) | (0u << 6),
-                              1u | (0u << 2) | (2u << 4) | (1u << 6), 1u | (2u << 2) | (0u << 4) | (1u << 6)};
-  return (int)((tables[p] >> (2 * (my * 2 + mx))) & 3u);
+  constexpr unsigned t0 = 0x0u | (1u << 2) | (1u << 4) | (2u << 6), t1 = 2u | (1u << 2) | (1u << 4) | (0u << 6);
+  constexpr unsigned t2 = 1u | (0u << 2) | (2u << 4) | (1u << 6), t3 = 1u | (2u << 2) | (0u << 4) | (1u << 6);
+  constexpr unsigned all = t0 | (t1 << 8) | (t2 << 16) | (t3 << 24);
+  return (int)((all >> (8 * p + 2 * ((y & 1) * 2 + (x & 1)))) & 3u);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 // src/main.rs:175-179
@@ -139,6 +139,149 @@ __global__ void k_combine(const float* r, const float* g, const float* b, float*
   out[3 * i + 2] = fmaxf(g0 + bg2, 0.0f);
 }
 
+// ------------------------------------------------------------------ fused gradient method
+// The four passes above move about 70 bytes per pixel through HBM (three intermediate planes written
+// and read back).  k_gradient_fused runs them on one tile per workgroup with the planes in LDS: raw is
+// read once with a 5-pixel apron, rgb written once (about 20 bytes per pixel).  Every plane value is
+// computed by the same expressions in the same order as in the pass kernels, so the result is the same
+// bits; out-of-image coordinates are clamped before the LDS lookup, exactly as getf() clamps them.
+constexpr int kTW = 64, kTH = 16;              // output tile
+constexpr int kHR = 5, kHG = 3, kHS = 2;       // aprons: raw, green, red/blue planes
+constexpr int kRW = kTW + 2 * kHR, kRH = kTH + 2 * kHR;
+constexpr int kGW = kTW + 2 * kHG, kGH = kTH + 2 * kHG;
+constexpr int kSW = kTW + 2 * kHS, kSH = kTH + 2 * kHS;
+
+struct Tile {
+  int x0, y0, w, h, pattern;
+  const float* raw;  // LDS, kRW x kRH, origin (x0 - kHR, y0 - kHR)
+  float* g;          // LDS, kGW x kGH, origin (x0 - kHG, y0 - kHG)
+  float* r;          // LDS, kSW x kSH, origin (x0 - kHS, y0 - kHS)
+  float* b;
+  __device__ __forceinline__ float raw_at(int x, int y) const {
+    return raw[(clampi(y, 0, h - 1) - (y0 - kHR)) * kRW + (clampi(x, 0, w - 1) - (x0 - kHR))];
+  }
+  // value of colour plane c taken straight from the mosaic (src/main.rs:192-204)
+  __device__ __forceinline__ float plane_at(int x, int y, int c) const {
+    const int xx = clampi(x, 0, w - 1), yy = clampi(y, 0, h - 1);
+    return cfa_at(xx, yy, pattern) == c ? raw[(yy - (y0 - kHR)) * kRW + (xx - (x0 - kHR))] : 0.0f;
+  }
+  __device__ __forceinline__ int gi(int x, int y) const {
+    return (clampi(y, 0, h - 1) - (y0 - kHG)) * kGW + (clampi(x, 0, w - 1) - (x0 - kHG));
+  }
+  __device__ __forceinline__ int si(int x, int y) const {
+    return (clampi(y, 0, h - 1) - (y0 - kHS)) * kSW + (clampi(x, 0, w - 1) - (x0 - kHS));
+  }
+};
+
+__global__ void __launch_bounds__(256) k_gradient_fused(const float* raw, float* out, int w, int h, int pattern) {
+  __shared__ float s_raw[kRW * kRH];
+  __shared__ float s_g[kGW * kGH];
+  __shared__ float s_r[kSW * kSH];
+  __shared__ float s_b[kSW * kSH];
+  Tile t;
+  t.x0 = blockIdx.x * kTW; t.y0 = blockIdx.y * kTH; t.w = w; t.h = h; t.pattern = pattern;
+  t.raw = s_raw; t.g = s_g; t.r = s_r; t.b = s_b;
+  const int tid = threadIdx.x;
+  // mosaic with apron (only in-image cells are ever read)
+  for (int k = tid; k < kRW * kRH; k += 256) {
+    const int x = t.x0 - kHR + k % kRW, y = t.y0 - kHR + k / kRW;
+    if (x >= 0 && y >= 0 && x < w && y < h) s_raw[k] = raw[(size_t)y * w + x];
+  }
+  __syncthreads();
+  // green plane (k_green)
+  for (int k = tid; k < kGW * kGH; k += 256) {
+    const int x = t.x0 - kHG + k % kGW, y = t.y0 - kHG + k / kGW;
+    if (x < 0 || y < 0 || x >= w || y >= h) continue;
+    const int c = cfa_at(x, y, pattern);
+    if (c == CFA_G) { s_g[k] = t.raw_at(x, y); continue; }
+    const float c0 = t.plane_at(x, y, c);
+    const float c_l2 = t.plane_at(x - 2, y, c), c_l1 = t.plane_at(x - 1, y, c);
+    const float c_r1 = t.plane_at(x + 1, y, c), c_r2 = t.plane_at(x + 2, y, c);
+    const float c_u2 = t.plane_at(x, y - 2, c), c_u1 = t.plane_at(x, y - 1, c);
+    const float c_d1 = t.plane_at(x, y + 1, c), c_d2 = t.plane_at(x, y + 2, c);
+    const float g_l1 = t.plane_at(x - 1, y, CFA_G), g_r1 = t.plane_at(x + 1, y, CFA_G);
+    const float g_u1 = t.plane_at(x, y - 1, CFA_G), g_d1 = t.plane_at(x, y + 1, CFA_G);
+    const float grad_h = fabsf(g_l1 - g_r1) + fabsf(2.0f * c0 - c_l2 - c_r2) * 0.5f + fabsf(c_l1 - c_r1);
+    const float grad_v = fabsf(g_u1 - g_d1) + fabsf(2.0f * c0 - c_u2 - c_d2) * 0.5f + fabsf(c_u1 - c_d1);
+    const float gh = 0.5f * (g_l1 + g_r1) + 0.25f * (2.0f * c0 - c_l2 - c_r2);
+    const float gv = 0.5f * (g_u1 + g_d1) + 0.25f * (2.0f * c0 - c_u2 - c_d2);
+    const float wh = 1.0f / (1e-6f + grad_h * grad_h);
+    const float wv = 1.0f / (1e-6f + grad_v * grad_v);
+    s_g[k] = (wh * gh + wv * gv) / (wh + wv);
+  }
+  __syncthreads();
+  // red and blue at green sites, raw / 0 at red and blue sites (k_rb_at_g)
+  for (int k = tid; k < kSW * kSH; k += 256) {
+    const int x = t.x0 - kHS + k % kSW, y = t.y0 - kHS + k / kSW;
+    if (x < 0 || y < 0 || x >= w || y >= h) continue;
+    const int c = cfa_at(x, y, pattern);
+    if (c == CFA_R) { s_r[k] = t.raw_at(x, y); s_b[k] = 0.0f; continue; }
+    if (c == CFA_B) { s_b[k] = t.raw_at(x, y); s_r[k] = 0.0f; continue; }
+    const float g0 = s_g[t.gi(x, y)];
+    const bool has_red_h = cfa_at(x - 1, y, pattern) == CFA_R || cfa_at(x + 1, y, pattern) == CFA_R;
+    const bool has_red_v = cfa_at(x, y - 1, pattern) == CFA_R || cfa_at(x, y + 1, pattern) == CFA_R;
+    const bool has_blue_h = cfa_at(x - 1, y, pattern) == CFA_B || cfa_at(x + 1, y, pattern) == CFA_B;
+    const bool has_blue_v = cfa_at(x, y - 1, pattern) == CFA_B || cfa_at(x, y + 1, pattern) == CFA_B;
+    float r_est, b_est;
+    if (has_red_h)
+      r_est = 0.5f * (t.plane_at(x - 1, y, CFA_R) + t.plane_at(x + 1, y, CFA_R)) -
+              0.5f * (s_g[t.gi(x - 1, y)] + s_g[t.gi(x + 1, y)]) + g0;
+    else if (has_red_v)
+      r_est = 0.5f * (t.plane_at(x, y - 1, CFA_R) + t.plane_at(x, y + 1, CFA_R)) -
+              0.5f * (s_g[t.gi(x, y - 1)] + s_g[t.gi(x, y + 1)]) + g0;
+    else
+      r_est = g0;
+    if (has_blue_h)
+      b_est = 0.5f * (t.plane_at(x - 1, y, CFA_B) + t.plane_at(x + 1, y, CFA_B)) -
+              0.5f * (s_g[t.gi(x - 1, y)] + s_g[t.gi(x + 1, y)]) + g0;
+    else if (has_blue_v)
+      b_est = 0.5f * (t.plane_at(x, y - 1, CFA_B) + t.plane_at(x, y + 1, CFA_B)) -
+              0.5f * (s_g[t.gi(x, y - 1)] + s_g[t.gi(x, y + 1)]) + g0;
+    else
+      b_est = g0;
+    s_r[k] = r_est;
+    s_b[k] = b_est;
+  }
+  __syncthreads();
+  // the missing colour at red and blue sites from the four diagonal neighbours (k_rb_diag), on the tile
+  // and one ring around it.  A site reads only sites this pass does not write (or itself, through
+  // clamping, before its own write), so doing it in place is safe without a second buffer.
+  for (int k = tid; k < (kTW + 2) * (kTH + 2); k += 256) {
+    const int x = t.x0 - 1 + k % (kTW + 2), y = t.y0 - 1 + k / (kTW + 2);
+    if (x < 0 || y < 0 || x >= w || y >= h) continue;
+    const int c = cfa_at(x, y, pattern);
+    if (c == CFA_G) continue;
+    float* dst = (c == CFA_R) ? s_b : s_r;
+    const float g0 = s_g[t.gi(x, y)];
+    const float est = 0.25f * ((dst[t.si(x - 1, y - 1)] - s_g[t.gi(x - 1, y - 1)]) +
+                               (dst[t.si(x + 1, y - 1)] - s_g[t.gi(x + 1, y - 1)]) +
+                               (dst[t.si(x - 1, y + 1)] - s_g[t.gi(x - 1, y + 1)]) +
+                               (dst[t.si(x + 1, y + 1)] - s_g[t.gi(x + 1, y + 1)])) + g0;
+    dst[t.si(x, y)] = est;
+  }
+  __syncthreads();
+  // chroma refinement and output (k_combine)
+  for (int k = tid; k < kTW * kTH; k += 256) {
+    const int x = t.x0 + k % kTW, y = t.y0 + k / kTW;
+    if (x >= w || y >= h) continue;
+    const float gh = fabsf(s_g[t.gi(x - 1, y)] - s_g[t.gi(x + 1, y)]);
+    const float gv = fabsf(s_g[t.gi(x, y - 1)] - s_g[t.gi(x, y + 1)]);
+    const float w_h = 1.0f / (1e-6f + gh);
+    const float w_v = 1.0f / (1e-6f + gv);
+    const float rgh = 0.5f * ((s_r[t.si(x - 1, y)] - s_g[t.gi(x - 1, y)]) + (s_r[t.si(x + 1, y)] - s_g[t.gi(x + 1, y)]));
+    const float rgv = 0.5f * ((s_r[t.si(x, y - 1)] - s_g[t.gi(x, y - 1)]) + (s_r[t.si(x, y + 1)] - s_g[t.gi(x, y + 1)]));
+    const float bgh = 0.5f * ((s_b[t.si(x - 1, y)] - s_g[t.gi(x - 1, y)]) + (s_b[t.si(x + 1, y)] - s_g[t.gi(x + 1, y)]));
+    const float bgv = 0.5f * ((s_b[t.si(x, y - 1)] - s_g[t.gi(x, y - 1)]) + (s_b[t.si(x, y + 1)] - s_g[t.gi(x, y + 1)]));
+    const float rg2 = (w_h * rgh + w_v * rgv) / (w_h + w_v);
+    const float bg2 = (w_h * bgh + w_v * bgv) / (w_h + w_v);
+    const float g0 = s_g[t.gi(x, y)];
+    const size_t i = (size_t)y * w + x;
+    out[3 * i + 0] = fmaxf(g0 + rg2, 0.0f);
+    out[3 * i + 1] = fmaxf(g0, 0.0f);
+    out[3 * i + 2] = fmaxf(g0 + bg2, 0.0f);
+  }
+}
+
 // src/main.rs:344-401
 __global__ void k_bilinear(const float* raw, float* out, int w, int h, int pattern) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -178,6 +321,13 @@ void launch_demosaic(const float* d_raw, float* d_out, float* d_tmp, int w, int 
   const dim3 grid((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4));
   if (algo == 1) {
     k_bilinear<<<grid, block, 0, s>>>(d_raw, d_out, w, h, pattern);
+    PT_KCHECK2();
+    return;
+  }
+  static const bool passes = getenv("PT_DEMOSAIC_PASSES") != nullptr;  // the four-pass form, for comparison
+  if (!passes) {
+    const dim3 tiles((unsigned)((w + kTW - 1) / kTW), (unsigned)((h + kTH - 1) / kTH));
+    k_gradient_fused<<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, pattern);
     PT_KCHECK2();
     return;
   }
