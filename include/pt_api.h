@@ -169,6 +169,23 @@ PT_EXPORT int pt_render_accumulate_device(int w, int h, int sample_begin, int sa
 PT_EXPORT int pt_render_adaptive_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth,
                                                    int frame, float noise_threshold, int min_adaptive_samples,
                                                    float* d_sum_rgb, float* d_count);
+/* Adaptive share with ONE noise test for all ranks (the progressive reduce the per-launch test of
+ * optix_device.cu:1011-1060 needs once the samples of a pixel live on several GPUs).  Every rank calls this
+ * with its own [sample_begin, sample_begin + sample_count) and the same total_spp (samples per pixel of all
+ * ranks together), frame, threshold and minimum.  Rounds follow pt_set_adaptive_round counted in samples of
+ * all ranks; a rank renders its proportional part of each round.  At every round boundary, and once more
+ * when the render is finished, the library writes 8 floats per pixel into d_stats (device, w*h*8: sum r g b,
+ * samples taken, sum of squares r g b, 0), waits for its stream and calls reduce(user), which must replace
+ * d_stats by its sum over all ranks (an in-place all-reduce) and return 0 once the result is visible to the
+ * device; a NULL reduce means one rank.  The noise test then runs on the totals, so all ranks keep the same
+ * pixels active and make the same number of reduce calls.  On return d_stats holds the totals of the
+ * finished render: mean = sum / samples.  Returns 0, -1 for bad arguments (NULL d_stats, threshold <= 0,
+ * sample_count <= 0 or > total_spp), or the first non-zero value reduce returned. */
+typedef int (*pt_reduce_fn)(void* user);
+PT_EXPORT int pt_render_adaptive_shared_device(int w, int h, int sample_begin, int sample_count, int total_spp,
+                                               int max_depth, int frame, float noise_threshold,
+                                               int min_adaptive_samples, float* d_stats, pt_reduce_fn reduce,
+                                               void* user);
 /* d_rgb (w*h*3, device) -> mosaic d_raw (w*h, device); value = max(channel / divisor, 0). */
 PT_EXPORT int pt_mosaic_device(const float* d_rgb, int w, int h, int pattern, float divisor, float* d_raw);
 

@@ -79,6 +79,10 @@ void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, 
                         const int* started, int w, int h, int pattern, int min_samples, int spp, float threshold,
                         hipStream_t s);
 
+// per-pixel statistics as 8 floats (sum rgb, samples, sum of squares rgb, 0) and back; count = round(samples)
+void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, float* stats, uint32_t npx, hipStream_t s);
+void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx, hipStream_t s);
+
 // profiling build (-DPT_PROFILE) only: section counters, (waves, lanes) pairs; returns the number of sections
 int read_profile_counters(unsigned long long* out64);
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);

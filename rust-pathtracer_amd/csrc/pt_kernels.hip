@@ -728,6 +728,26 @@ __global__ void __launch_bounds__(256) k_noise_select(const uint32_t* active, ui
   }
 }
 
+// Statistics of every pixel as eight floats (sum r g b, samples taken, sum of squares r g b, 0): the form in
+// which ranks of a sample-sharded adaptive render add their shares together, and its inverse.
+__global__ void k_pack_stats(const q4* acc, const q4* acc2, const int* started, float* stats, uint32_t npx) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const q4 a = acc[i], b = acc2[i];
+    q4* out = reinterpret_cast<q4*>(stats) + 2 * (size_t)i;
+    out[0] = q4{a.x, a.y, a.z, (float)started[i]};
+    out[1] = q4{b.x, b.y, b.z, 0.f};
+  }
+}
+__global__ void k_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const q4* in = reinterpret_cast<const q4*>(stats) + 2 * (size_t)i;
+    const q4 a = in[0], b = in[1];
+    acc[i] = q4{a.x, a.y, a.z, 0.f};
+    acc2[i] = q4{b.x, b.y, b.z, 0.f};
+    count[i] = (int)(a.w + 0.5f);
+  }
+}
+
 // ------------------------------------------------------------------------ utilities
 __global__ void k_iota(uint32_t* dst, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = i;
@@ -826,6 +846,14 @@ int read_profile_counters(unsigned long long* out64) {
 }
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {
   k_iota<<<1024, 256, 0, s>>>(dst, n);
+  PT_KCHECK();
+}
+void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, float* stats, uint32_t npx, hipStream_t s) {
+  k_pack_stats<<<1024, 256, 0, s>>>(acc, acc2, started, stats, npx);
+  PT_KCHECK();
+}
+void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx, hipStream_t s) {
+  k_unpack_stats<<<1024, 256, 0, s>>>(stats, acc, acc2, count, npx);
   PT_KCHECK();
 }
 void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, const q4* acc, const q4* acc2,

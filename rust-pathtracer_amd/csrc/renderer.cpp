@@ -498,10 +498,20 @@ void ensure_adaptive(State& s) {
   s.adaptive.own_noise = dev_alloc<float>(px);
 }
 
+// Statistics shared between the ranks of a sample-sharded adaptive render: at every round boundary each
+// rank packs (sum, samples, sum of squares) of all pixels into `stats`, `reduce` adds the ranks' buffers
+// together in place, and the noise test runs on the totals, so every rank keeps the same pixels active.
+struct SharedStats {
+  float* stats;     // device, 8 floats per pixel
+  int total_spp;    // samples per pixel of all ranks together
+  int (*reduce)(void* user);
+  void* user;
+};
+
 // sample_begin > 0: this call's samples are the global samples [sample_begin, sample_begin + spp) of every
-// pixel (one rank's share); the noise test then runs on this share's own statistics.
-void render_adaptive(State& s, int sample_begin, int spp, int max_depth, int frame, bool strict, float threshold,
-                     int min_samples) {
+// pixel (one rank's share).  Without `shared` the noise test runs on this share's own statistics.
+int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int frame, bool strict, float threshold,
+                    int min_samples, const SharedStats* shared = nullptr) {
   ensure_adaptive(s);
   RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict);
   p.chunks = 1;
@@ -510,6 +520,23 @@ void render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fra
   RenderLoop loop(s, p);
   s.last_chunks = 1;
   const uint32_t npx = p.npx;
+  if (shared && !s.shared_acc) {
+    s.shared_acc = dev_alloc<q4>(npx);
+    s.shared_acc2 = dev_alloc<q4>(npx);
+    s.shared_n = dev_alloc<int>(npx);
+  }
+  // the round schedule counts samples of all ranks; a rank's target is its proportional part of it
+  const int total = shared ? std::max(shared->total_spp, spp) : spp;
+  auto local_target = [&](int t) {
+    return shared ? (int)std::min<long long>(spp, ((long long)t * spp + total - 1) / total) : t;
+  };
+  auto exchange = [&]() -> int {
+    launch_pack_stats(s.acc, s.acc2, s.started, shared->stats, npx, s.stream);
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    const int rc = shared->reduce ? shared->reduce(shared->user) : 0;
+    HIP_CHECK(hipSetDevice(s.device));
+    return rc;
+  };
   // strict mode replays the reference's 4-sample launches, so it is tested at that cadence
   const bool doubling = !strict && g_adaptive_round < 0;
   const int round = strict ? 4 : std::max(std::abs(g_adaptive_round), 1);
@@ -519,30 +546,43 @@ void render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fra
   HIP_CHECK(hipMemsetAsync(s.adaptive.noise_map, 0, (size_t)npx * sizeof(uint32_t), s.stream));
   launch_iota(s.adaptive.active[0], npx, s.stream);
   uint32_t n_active = npx;
-  int which = 0, done = 0;
+  int which = 0, done = 0, done_local = 0, rc = 0;
   s.adaptive_rounds = 0;
-  while (n_active > 0 && done < spp) {
+  while (n_active > 0 && done < total) {
     int target = next_target(done);
-    while (target < min_samples && target < spp) target = next_target(target);  // no test before min_samples
-    target = std::min(target, spp);
-    loop.p.sample_count = target;
-    loop.p.chunk_spp = target;
-    HIP_CHECK(hipMemcpyAsync(s.queue[0], s.adaptive.active[which], (size_t)n_active * sizeof(uint32_t),
-                             hipMemcpyDeviceToDevice, s.stream));
-    loop.drain(n_active);
+    while (target < min_samples && target < total) target = next_target(target);  // no test before min_samples
+    target = std::min(target, total);
+    const int mine = local_target(target);
+    if (mine > done_local) {
+      loop.p.sample_count = mine;
+      loop.p.chunk_spp = mine;
+      HIP_CHECK(hipMemcpyAsync(s.queue[0], s.adaptive.active[which], (size_t)n_active * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, s.stream));
+      loop.drain(n_active);
+      done_local = mine;
+    }
     done = target;
     s.adaptive_rounds++;
-    if (done >= spp) break;
+    if (done >= total) break;
+    const q4 *t_acc = s.acc, *t_acc2 = s.acc2;
+    const int* t_n = s.started;
+    if (shared) {
+      if ((rc = exchange()) != 0) break;
+      launch_unpack_stats(shared->stats, s.shared_acc, s.shared_acc2, s.shared_n, npx, s.stream);
+      t_acc = s.shared_acc; t_acc2 = s.shared_acc2; t_n = s.shared_n;
+    }
     HIP_CHECK(hipMemsetAsync(s.adaptive.count, 0, sizeof(uint32_t), s.stream));
-    launch_noise_round(s.adaptive, which, n_active, s.acc, s.acc2, s.started, s.width, s.height, s.bayer_pattern,
-                       min_samples, spp, threshold, s.stream);
+    launch_noise_round(s.adaptive, which, n_active, t_acc, t_acc2, t_n, s.width, s.height, s.bayer_pattern,
+                       min_samples, total, threshold, s.stream);
     HIP_CHECK(hipMemcpyAsync(s.h_counters + 2 * CNT_WORDS, s.adaptive.count, sizeof(uint32_t), hipMemcpyDeviceToHost,
                              s.stream));
     HIP_CHECK(hipStreamSynchronize(s.stream));
     n_active = s.h_counters[2 * CNT_WORDS];
     which ^= 1;
   }
+  if (shared && rc == 0) rc = exchange();  // the totals of the finished render
   loop.end();
+  return rc;
 }
 
 int render_mean(State& s, int spp, int max_depth, float noise_threshold, int min_adaptive_samples) {
@@ -584,6 +624,7 @@ State::~State() {
   dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise);
+  dev_free(shared_acc); dev_free(shared_acc2); dev_free(shared_n);
   dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_demosaic_tmp);
   dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid);
   if (h_counters) (void)hipHostFree(h_counters);
@@ -740,6 +781,16 @@ int pt_render_adaptive_accumulate_device(int w, int h, int sample_begin, int sam
   launch_add_counts(s.started, d_count, npx, s.last_chunks, s.stream);
   HIP_CHECK(hipStreamSynchronize(s.stream));
   return 0;
+}
+
+int pt_render_adaptive_shared_device(int w, int h, int sample_begin, int sample_count, int total_spp, int max_depth,
+                                     int frame, float noise_threshold, int min_adaptive_samples, float* d_stats,
+                                     pt_reduce_fn reduce, void* user) {
+  State& s = ensure_handle(w, h);
+  if (!d_stats || sample_count <= 0 || total_spp < sample_count || !(noise_threshold > 0.0f)) return -1;
+  const SharedStats shared{d_stats, total_spp, reduce, user};
+  return render_adaptive(s, sample_begin, sample_count, max_depth, frame, false, noise_threshold, min_adaptive_samples,
+                         &shared);
 }
 
 int pt_mosaic_device(const float* d_rgb, int w, int h, int pattern, float divisor, float* d_raw) {

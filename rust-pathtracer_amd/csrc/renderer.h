@@ -69,6 +69,8 @@ struct State {
   q4* acc2 = nullptr;
   AdaptiveBuffers adaptive{};
   int adaptive_rounds = 0;
+  q4 *shared_acc = nullptr, *shared_acc2 = nullptr;  // statistics summed over ranks (shared noise test)
+  int* shared_n = nullptr;
 
   // outputs
   float* d_out_rgb = nullptr;

@@ -44,6 +44,7 @@ class PathRec(C.Structure):  # pt_path_rec
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
 _u32p = C.POINTER(C.c_uint32)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)  # pt_reduce_fn
 _u64p = C.POINTER(C.c_uint64)
 
 # name -> (restype, argtypes); also the list of symbols include/pt_api.h declares.
@@ -82,6 +83,7 @@ SIGNATURES = {
     "pt_get_frame": (C.c_int, []),
     "pt_render_accumulate_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pt_render_adaptive_accumulate_device": (C.c_int, [C.c_int] * 6 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "pt_render_adaptive_shared_device": (C.c_int, [C.c_int] * 7 + [C.c_float, C.c_int, C.c_void_p, REDUCE_FN, C.c_void_p]),
     "pt_mosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "pt_demosaic_f32": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "pt_demosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -179,6 +181,33 @@ def render_adaptive_accumulate_device(sum_tensor, count_tensor, w, h, sample_beg
                                                     count_tensor.data_ptr())
     if rc != 0:
         raise RuntimeError(f"pt_render_adaptive_accumulate_device returned {rc}")
+
+
+def render_adaptive_shared_device(stats_tensor, w, h, sample_begin, sample_count, total_spp, max_depth, frame,
+                                  noise_threshold, min_adaptive_samples=32, reduce=None):
+    """One rank's share of an adaptive render whose noise test runs on the statistics of all ranks.
+    stats_tensor: CUDA float32, w*h*8; reduce(): sums stats_tensor over the ranks in place and leaves the
+    result visible to the device (called at every round boundary and once at the end; None: one rank).
+    On return stats_tensor.view(h, w, 8) holds (sum rgb, samples, sum of squares rgb, 0) of all ranks."""
+    t = stats_tensor
+    assert t.is_cuda and t.dtype.is_floating_point and t.element_size() == 4 and t.numel() == w * h * 8 and t.is_contiguous()
+    failure = []
+
+    def _call(_user):
+        try:
+            reduce()
+            return 0
+        except BaseException as e:  # an exception must not unwind through the C frames
+            failure.append(e)
+            return 1
+
+    cb = REDUCE_FN(_call) if reduce is not None else REDUCE_FN()
+    rc = lib().pt_render_adaptive_shared_device(w, h, sample_begin, sample_count, total_spp, max_depth, frame,
+                                                noise_threshold, min_adaptive_samples, t.data_ptr(), cb, None)
+    if failure:
+        raise failure[0]
+    if rc != 0:
+        raise RuntimeError(f"pt_render_adaptive_shared_device returned {rc}")
 
 
 def demosaic(raw, pattern=0, algo=0):

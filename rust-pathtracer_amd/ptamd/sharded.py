@@ -65,3 +65,41 @@ def render_sharded_adaptive(render_share, w, h, begin, count, group=None, device
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     mean = sums.view(h, w, 3) / counts.clamp(min=1.0).view(h, w, 1)
     return mean, counts.view(h, w)
+
+
+def render_sharded_adaptive_shared(render_share, w, h, begin, count, total_spp, group=None, device=None):
+    """Adaptive render with one noise test for all ranks.  render_share(stats_tensor, begin, count, total_spp,
+    reduce) renders this rank's samples round by round and calls reduce() whenever the ranks' statistics
+    (stats_tensor: w*h*8 floats per pixel: sum rgb, samples, sum of squares rgb, 0) have to be added
+    together -- at every round boundary and once when it has finished, the same number of times on every
+    rank.  Returns (mean image [h,w,3], samples per pixel [h,w]), identical on all ranks."""
+    stats = torch.zeros(w * h * 8, dtype=torch.float32, device=device)
+    many = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def reduce():
+        if many:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        if stats.is_cuda:
+            torch.cuda.synchronize(stats.device)
+
+    render_share(stats, begin, count, total_spp, reduce)
+    v = stats.view(h, w, 8)
+    counts = v[..., 3]
+    return v[..., 0:3] / counts.clamp(min=1.0).unsqueeze(-1), counts
+
+
+class DeviceSharedAdaptiveRenderer:
+    """render_share callable backed by pt_render_adaptive_shared_device on this rank's GPU."""
+
+    def __init__(self, w, h, max_depth, frame, noise_threshold, min_adaptive_samples, device):
+        import ptamd
+        self.pt = ptamd
+        self.w, self.h, self.max_depth, self.frame = w, h, max_depth, frame
+        self.threshold, self.min_samples = noise_threshold, min_adaptive_samples
+        self.device = torch.device(device)
+        ptamd.lib().pt_set_device(self.device.index or 0)
+
+    def __call__(self, stats, begin, count, total_spp, reduce):
+        torch.cuda.synchronize(self.device)  # stats was zeroed on torch's stream
+        self.pt.render_adaptive_shared_device(stats, self.w, self.h, begin, count, total_spp, self.max_depth,
+                                              self.frame, self.threshold, self.min_samples, reduce)

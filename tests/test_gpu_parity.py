@@ -14,6 +14,7 @@ from test_host_logic import HcRec, P, check_shade_against_oracle, make_shade_cas
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
+ROOT = os.path.dirname(HERE)
 
 
 def rel_rmse(img, ref):
@@ -706,6 +707,106 @@ def test_adaptive_shares_accumulate(gpu):
     gpu.render_adaptive_accumulate_device(s2, n2, w, h, 0, 48, 32, 5, 0.0, 32)
     gpu.render_accumulate_device(s3, w, h, 0, 48, 32, 5)
     assert torch.equal(s2, s3) and (n2 == 48).all()
+
+
+def test_adaptive_shared_one_rank_is_plain_adaptive(gpu):
+    """The shared-statistics entry point with one rank (no reduce) makes the decisions of the per-share one:
+    same sums, same counts, bit for bit; the statistics it returns are those of the render."""
+    import torch
+    from ptamd import sharded
+    w, h, spp, thr = 96, 32, 128, 1.5
+    dev = torch.device("cuda:0")
+    gpu.lib().pt_set_adaptive_round(-32)  # doubling rounds, the library's default
+    sums = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+    counts = torch.zeros(w * h, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu.render_adaptive_accumulate_device(sums, counts, w, h, 0, spp, 32, 5, thr, 32)
+    calls = []
+    stats = torch.zeros(w * h * 8, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu.render_adaptive_shared_device(stats, w, h, 0, spp, spp, 32, 5, thr, 32, reduce=lambda: calls.append(1))
+    v = stats.view(w * h, 8)
+    assert torch.equal(v[:, 0:3].reshape(-1), sums) and torch.equal(v[:, 3], counts)
+    assert (v[:, 7] == 0).all() and (v[:, 4:7] >= 0).all()
+    c = counts.cpu().numpy()
+    assert set(np.unique(c)) <= {32.0, 64.0, 128.0} and len(np.unique(c)) > 1
+    assert len(calls) == 3  # after 32 and 64 samples, and the totals at the end
+    # NULL reduce and the helper give the same
+    renderer = sharded.DeviceSharedAdaptiveRenderer(w, h, 32, 5, thr, 32, dev)
+    mean, cnt = sharded.render_sharded_adaptive_shared(renderer, w, h, 0, spp, spp, device=dev)
+    assert torch.equal(cnt.reshape(-1), counts)
+    assert torch.equal(mean.reshape(-1, 3), sums.view(-1, 3) / counts.unsqueeze(1))
+    # argument checks; an exception in reduce comes back as itself
+    L = gpu.lib()
+    assert L.pt_render_adaptive_shared_device(w, h, 0, spp, spp, 32, 5, 1.0, 32, None, gpu.REDUCE_FN(), None) == -1
+    assert L.pt_render_adaptive_shared_device(w, h, 0, spp, spp - 1, 32, 5, 1.0, 32, stats.data_ptr(), gpu.REDUCE_FN(), None) == -1
+    assert L.pt_render_adaptive_shared_device(w, h, 0, spp, spp, 32, 5, 0.0, 32, stats.data_ptr(), gpu.REDUCE_FN(), None) == -1
+
+    def boom():
+        raise KeyError("reduce failed")
+    with pytest.raises(KeyError):
+        gpu.render_adaptive_shared_device(stats, w, h, 0, spp, spp, 32, 5, thr, 32, reduce=boom)
+    out = gpu.render_rgb(w, h, 8)  # the renderer is usable afterwards
+    assert np.isfinite(out).all()
+
+
+_SHARED_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import ptamd
+from ptamd import sharded
+rank, world = int(sys.argv[3]), 2
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=world)
+w, h, per, thr = 96, 32, 64, 1.5
+dev = torch.device("cuda:0")
+renderer = sharded.DeviceSharedAdaptiveRenderer(w, h, 32, 5, thr, 32, dev)
+begin, count = sharded.chunk_of(rank, per)
+mean, cnt = sharded.render_sharded_adaptive_shared(renderer, w, h, begin, count, world * per, device=dev)
+own, rounds = ptamd.sample_counts(w, h)
+np.savez(sys.argv[4] + "/rank%d.npz" % rank, mean=mean.cpu().numpy(), cnt=cnt.cpu().numpy(), own=own, rounds=rounds)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_adaptive_shared_two_ranks(gpu, tmp_path):
+    """Two ranks (two processes on this GPU, gloo) render 64 samples each of a 128-sample adaptive render with
+    the noise test on their summed statistics: both end with the same image and the same counts, every
+    pixel took the same number of samples on both ranks, and rounds fall at 32, 64 and 128 samples of both
+    ranks together."""
+    import socket
+    import sys
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    script = tmp_path / "shared_worker.py"
+    script.write_text(_SHARED_WORKER)
+    pkg = os.path.join(ROOT, "rust-pathtracer_amd")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), pkg, str(port), str(r), str(tmp_path)], env=env)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    a, b = (np.load(tmp_path / f"rank{r}.npz") for r in range(2))
+    assert np.array_equal(a["mean"], b["mean"]) and np.array_equal(a["cnt"], b["cnt"])
+    assert np.array_equal(a["own"], b["own"]) and int(a["rounds"]) == int(b["rounds"]) == 3
+    assert np.array_equal(a["own"] * 2, a["cnt"].astype(np.int32))
+    cnt = a["cnt"]
+    assert set(np.unique(cnt)) <= {32.0, 64.0, 128.0} and len(np.unique(cnt)) > 1
+    assert (cnt[:, 0] == 32).all()  # black bars stop at the first shared test: 16 samples on each rank
+    gpu.lib().pt_set_adaptive_round(-32)  # what the fresh worker processes ran with
+    gpu.lib().pt_set_frame(4)
+    full = gpu.render_rgb(96, 32, 128)  # frame 5, fixed count
+    assert abs(a["mean"].mean() - full.mean()) / full.mean() < 0.05
+    # one rank with the same total makes its decisions at the same totals: similar count map
+    import torch
+    stats = torch.zeros(96 * 32 * 8, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu.render_adaptive_shared_device(stats, 96, 32, 0, 128, 128, 32, 5, 1.5, 32)
+    one = stats.view(32, 96, 8)[..., 3].cpu().numpy()
+    assert (one == cnt).mean() > 0.6
 
 
 # ------------------------------------------------------------------ a16 / a17 demosaic + EXR

@@ -446,3 +446,53 @@ def test_sample_sharded_reduce_two_ranks(hostcheck, tmp_path):
     from ptamd import sharded
     assert sharded.split_samples(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
     assert sharded.chunk_of(3, 512) == (1536, 512)
+
+
+_SHARED_WORKER = r'''
+import sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ptamd import sharded
+rank = int(sys.argv[3])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=2)
+w, h = 6, 4
+calls = []
+def render_share(stats, begin, count, total, reduce):
+    # three rounds; in each this rank adds its own statistics on top of the totals of the round before
+    local = torch.zeros(w * h, 8)
+    for rnd in range(3):
+        local[:, 0:3] += (rank + 1) * (rnd + 1)
+        local[:, 3] += count / 4
+        local[:, 4:7] += ((rank + 1) * (rnd + 1)) ** 2
+        stats.copy_(local.reshape(-1))
+        reduce()
+        calls.append(stats.clone())
+begin, count = sharded.chunk_of(rank, 8)
+mean, cnt = sharded.render_sharded_adaptive_shared(render_share, w, h, begin, count, 16)
+np.savez(sys.argv[4] + "/r%d.npz" % rank, mean=mean.numpy(), cnt=cnt.numpy(), first=calls[0].numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shared_adaptive_reduce_two_ranks(tmp_path):
+    """The reduce step of the shared noise test over two gloo ranks: after every call all ranks hold the sum of
+    the ranks' statistics, and the image is sum / samples of the last one."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    script = tmp_path / "shared_worker.py"
+    script.write_text(_SHARED_WORKER)
+    pkg = os.path.join(ROOT, "rust-pathtracer_amd")
+    procs = [subprocess.Popen([sys.executable, str(script), pkg, str(port), str(r), str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b = (np.load(tmp_path / f"r{r}.npz") for r in range(2))
+    for k in ("mean", "cnt", "first"):
+        assert np.array_equal(a[k], b[k])
+    first = a["first"].reshape(-1, 8)
+    assert (first[:, 0] == 3).all() and (first[:, 3] == 4).all() and (first[:, 4] == 5).all()
+    # after three rounds: sums (1+2)*(1+2+3) = 18 over 2 * 3 * 2 = 12 samples
+    assert (a["cnt"] == 12).all() and np.allclose(a["mean"], 1.5)
