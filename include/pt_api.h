@@ -228,6 +228,12 @@ PT_EXPORT void pt_scene_cornell(void);
 PT_EXPORT void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv);
 PT_EXPORT void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                                   const float* materials11);
+/* Leaf items of the BVH: 1 (default) lets two consecutive triangles that form a parallelogram -- a quad
+ * split along a diagonal -- share one traversal record and one plane intersection, 0 keeps every triangle
+ * on its own, < 0 returns to the default (environment PT_BVH_PAIRS).  Results are the same primitives and
+ * distances either way; the tree is rebuilt at the next render.  No counterpart in the reference (the
+ * driver's GAS build is opaque, optix_wrapper.cpp:492-544). */
+PT_EXPORT void pt_set_bvh_pairing(int on);
 PT_EXPORT void pt_scene_info(int* n_triangles, int* n_bvh_nodes, int* bvh_depth, size_t* bvh_bytes);
 /* Copy out the active scene (tests compare it with the oracle's). Any pointer may be NULL. */
 PT_EXPORT void pt_scene_get(float* vertices, uint32_t* indices, float* normals, float* materials11);

@@ -43,6 +43,59 @@ struct Node2 {
 
 constexpr int kBins = 16;
 constexpr int kMaxLeaf = 3;
+constexpr uint32_t kNoPartner = 0xffffffffu;
+
+// What a leaf slot holds: one triangle, or two triangles that together form a parallelogram (a quad split
+// along a diagonal), which traversal tests with one plane intersection.
+struct Item {
+  uint32_t a, b;   // input triangles; b == kNoPartner: single
+  uint32_t code;   // 0x40 | k | sel1 << 2 | sel2 << 4 (see the record layout in pt_bvh.h), 0 for a single
+  float delta;     // how far b's own corner is from the exact parallelogram corner (max norm)
+};
+
+// Triangles A and B share an edge and B's third corner is A's third corner mirrored through the middle of
+// that edge (within rounding of the coordinates).
+bool try_pair(const float* verts, const uint32_t* idx, uint32_t A, uint32_t B, float vmag, Item& item) {
+  const uint32_t *ia = idx + 3 * (size_t)A, *ib = idx + 3 * (size_t)B;
+  const float* va[3];
+  const float* vb[3];
+  for (int m = 0; m < 3; ++m) { va[m] = verts + 3 * (size_t)ia[m]; vb[m] = verts + 3 * (size_t)ib[m]; }
+  auto same = [](const float* p, const float* q) { return p[0] == q[0] && p[1] == q[1] && p[2] == q[2]; };
+  int in_b[3] = {-1, -1, -1};  // for A's corner m: the equal corner of B
+  bool b_used[3] = {false, false, false};
+  int shared = 0;
+  for (int m = 0; m < 3; ++m)
+    for (int w = 0; w < 3; ++w)
+      if (!b_used[w] && in_b[m] < 0 && same(va[m], vb[w])) { in_b[m] = w; b_used[w] = true; shared++; }
+  if (shared != 2) return false;
+  int k = 0, kb = 0;
+  for (int m = 0; m < 3; ++m) if (in_b[m] < 0) k = m;
+  for (int w = 0; w < 3; ++w) if (!b_used[w]) kb = w;
+  const int i = (k + 1) % 3, j = (k + 2) % 3;
+  if (same(va[i], va[j])) return false;
+  double delta = 0.0, n[3], e1[3], e2[3];
+  for (int c = 0; c < 3; ++c) {
+    const double ideal = (double)va[i][c] + (double)va[j][c] - (double)va[k][c];
+    delta = std::max(delta, std::fabs((double)vb[kb][c] - ideal));
+    e1[c] = (double)va[1][c] - (double)va[0][c];
+    e2[c] = (double)va[2][c] - (double)va[0][c];
+  }
+  n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+  const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+  if (!(nn > 0.0) || !std::isfinite(nn)) return false;
+  if (!(delta <= std::ldexp((double)vmag, -21))) return false;
+  // mirroring sends A's corner i to j, j to i and k to B's own corner; weight c_m of the mirrored point
+  // belongs to the image of corner m
+  auto source_of = [&](int w) {  // which c_m is the weight of B's corner w
+    if (w == kb) return k;
+    return in_b[i] == w ? j : i;
+  };
+  item.a = A;
+  item.b = B;
+  item.code = 0x40u | (uint32_t)k | ((uint32_t)source_of(1) << 2) | ((uint32_t)source_of(2) << 4);
+  item.delta = (float)delta;
+  return true;
+}
 
 struct Builder {
   const float* verts;
@@ -314,6 +367,7 @@ struct Builder {
 struct Emitter {
   Builder& b;
   BvhBuildResult& out;
+  const std::vector<Item>& items;
   // for the binary node that becomes an 8-wide node: 8-wide nodes strictly below it, triangles in it
   // and below.  Known before emission, so every node's place in the arrays is fixed up front and
   // subtrees can be emitted by different threads into the same layout a single thread would produce.
@@ -364,8 +418,10 @@ struct Emitter {
     return total;
   }
 
-  // traversal record of a triangle (layout: TriRecord comment in pt_bvh.h), computed in double
-  void write_tri(uint32_t slot_index, uint32_t prim) {
+  // traversal record of a leaf item (layout: the record comment in pt_bvh.h), computed in double
+  void write_tri(uint32_t slot_index, uint32_t item_index) {
+    const Item& item = items[(size_t)item_index];
+    const uint32_t prim = item.a;
     const uint32_t* t = b.idx + 3 * (size_t)prim;
     double v[3][3];
     for (int k = 0; k < 3; ++k)
@@ -387,7 +443,13 @@ struct Emitter {
     const double norm1 = std::fabs(r1[0]) + std::fabs(r1[1]) + std::fabs(r1[2]);
     const double norm2 = std::fabs(r2[0]) + std::fabs(r2[1]) + std::fabs(r2[2]);
     // 16 ulps of the largest term of the dot products per unit of coordinate magnitude, both rows
-    const double eps = std::ldexp(norm1 + norm2, -20);
+    double eps = std::ldexp(norm1 + norm2, -20);
+    if (item.code) {
+      // the partner is tested as A's mirror image: widen the band by what its real corner is off by
+      eps += (norm1 + norm2) * (double)item.delta / std::max((double)out.vmag, 1e-30);
+      q[2].w = u2f(item.code);
+      q[3].w = u2f(item.b);
+    }
     q[0].w = (float)eps;
     q[1].x = (float)r1[0]; q[1].y = (float)r1[1]; q[1].z = (float)r1[2];
     q[2].x = (float)r2[0]; q[2].y = (float)r2[1]; q[2].z = (float)r2[2];
@@ -429,6 +491,11 @@ struct Emitter {
       }
       out.home_node[prim[i]] = node_index;
       out.home_mask[prim[i]] = mask;
+      if (f2u(out.tris[4 * (size_t)(first + i) + 2].w)) {  // the partner lies in the same plane
+        const uint32_t partner = f2u(out.tris[4 * (size_t)(first + i) + 3].w);
+        out.home_node[partner] = node_index;
+        out.home_mask[partner] = mask;
+      }
     }
   }
 
@@ -556,7 +623,11 @@ struct Emitter {
   }
 };
 
+int g_pairing = -1;  // -1: environment (PT_BVH_PAIRS, default on)
+
 }  // namespace
+
+void bvh_set_pairing(int on) { g_pairing = on < 0 ? -1 : (on ? 1 : 0); }
 
 BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int num_tris) {
   BvhBuildResult out;
@@ -574,13 +645,30 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   Builder b;
   b.verts = vertices;
   b.idx = indices;
-  b.prims.resize((size_t)num_tris);
+  for (size_t k = 0; k < 3 * (size_t)num_tris; ++k) {
+    const float* v = vertices + 3 * (size_t)indices[k];
+    out.vmag = std::max(out.vmag, std::max(std::fabs(v[0]), std::max(std::fabs(v[1]), std::fabs(v[2]))));
+  }
+  // Leaf items: a triangle and its successor in the input become one item when they are the two halves of
+  // a parallelogram (how quads arrive in a triangle list); everything else stays a single triangle.
+  const bool pairing = g_pairing >= 0 ? g_pairing != 0 : !(getenv("PT_BVH_PAIRS") && atoi(getenv("PT_BVH_PAIRS")) == 0);
+  std::vector<Item> items;
+  items.reserve((size_t)num_tris);
   for (int t = 0; t < num_tris; ++t) {
+    Item item{(uint32_t)t, kNoPartner, 0u, 0.f};
+    if (pairing && t + 1 < num_tris && try_pair(vertices, indices, (uint32_t)t, (uint32_t)t + 1u, out.vmag, item)) ++t;
+    items.push_back(item);
+  }
+  const int num_items = (int)items.size();
+  out.num_items = num_items;
+  b.prims.resize((size_t)num_items);
+  for (int it = 0; it < num_items; ++it) {
     Box bx;
     bx.reset();
-    for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)t + k]);
-    for (int k = 0; k < 3; ++k) out.vmag = std::max(out.vmag, std::max(std::fabs(bx.lo[k]), std::fabs(bx.hi[k])));
-    Builder::Prim& pr = b.prims[(size_t)t];
+    for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)items[(size_t)it].a + k]);
+    if (items[(size_t)it].b != kNoPartner)
+      for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)items[(size_t)it].b + k]);
+    Builder::Prim& pr = b.prims[(size_t)it];
     for (int k = 0; k < 3; ++k) {
       pr.c[k] = 0.5f * (bx.lo[k] + bx.hi[k]);
       // pad so that rays grazing a flat or grid-aligned box are not lost to rounding
@@ -589,9 +677,9 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
       bx.hi[k] += pad;
     }
     pr.box = bx;
-    pr.id = (uint32_t)t;
+    pr.id = (uint32_t)it;
   }
-  b.nodes2.resize(2 * (size_t)num_tris);
+  b.nodes2.resize(2 * (size_t)num_items);
   {
     const unsigned hw = std::thread::hardware_concurrency();
     const char* env = getenv("PT_BVH_THREADS");
@@ -603,25 +691,25 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
     return std::chrono::duration<double>(b2 - a).count();
   };
   const auto t0 = now();
-  const int root2 = b.build_root(num_tris);
+  const int root2 = b.build_root(num_items);
   const auto t1 = now();
   b.nodes2.resize((size_t)b.next_node.load());
-  b.order.resize((size_t)num_tris);
-  for (int t = 0; t < num_tris; ++t) b.order[(size_t)t] = b.prims[(size_t)t].id;
+  b.order.resize((size_t)num_items);
+  for (int t = 0; t < num_items; ++t) b.order[(size_t)t] = b.prims[(size_t)t].id;
   std::vector<Builder::Prim>().swap(b.prims);
   b.dp.resize(b.nodes2.size());
   b.compute_collapse(root2);
   const auto t2 = now();
-  out.tris.resize(4 * (size_t)num_tris);
+  out.tris.resize(4 * (size_t)num_items);
   out.home_node.assign((size_t)num_tris, 0u);
   out.home_mask.assign((size_t)num_tris, 0u);
-  Emitter em{b, out};
+  Emitter em{b, out, items};
   em.below.assign(b.nodes2.size(), 0u);
   const uint32_t nodes_below_root = em.count_below(root2);
   out.nodes.resize(1 + (size_t)nodes_below_root);
   out.depth = em.emit(0, root2, 1u, 0u);
   if (timing)
-    fprintf(stderr, "bvh build: %d triangles, binary tree %.2f s (%d threads), collapse %.2f s, emit %.2f s\n", num_tris,
+    fprintf(stderr, "bvh build: %d triangles in %d leaf items, binary tree %.2f s (%d threads), collapse %.2f s, emit %.2f s\n", num_tris, num_items,
             secs(t0, t1), b.max_threads, secs(t1, t2), secs(t2, now()));
   return out;
 }

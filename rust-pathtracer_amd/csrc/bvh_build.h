@@ -12,14 +12,19 @@ namespace pt {
 
 struct BvhBuildResult {
   std::vector<BvhNode> nodes;  // node 0 is the root
-  std::vector<q4> tris;        // 4 x q4 per triangle in leaf order (traversal records, see pt_bvh.h)
+  std::vector<q4> tris;        // 4 x q4 per leaf item in leaf order (traversal records, see pt_bvh.h)
   float vmag = 0.f;            // largest |coordinate| of any referenced vertex
   // per primitive: the node whose leaf slots hold it, and the bits (offsets in that node's triangle
   // range) of every triangle of that node lying in the same plane, itself included
   std::vector<uint32_t> home_node, home_mask;
   int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
   int num_tris = 0;
+  int num_items = 0;           // leaf items: single triangles, or two triangles forming a parallelogram
 };
+
+// Whether consecutive triangles that form a parallelogram share one leaf item (default: yes, unless the
+// environment says PT_BVH_PAIRS=0); on < 0 returns to that default.  Applies to the next build.
+void bvh_set_pairing(int on);
 
 // vertices: 3 floats each; indices: 3 per triangle.
 BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int num_tris);

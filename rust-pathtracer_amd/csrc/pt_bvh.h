@@ -103,11 +103,16 @@ PT_HD bool intersect_triangle(const RayShear& rs, f3 o, f3 v0, f3 v1, f3 v2, flo
   return true;
 }
 
-// Traversal copy of a triangle, 64 bytes: a precomputed affine map to "unit triangle" space.
-//   q0 = v0.xyz, eps     q1 = r1.xyz, primitive index bits     q2 = r2.xyz, -     q3 = n.xyz, -
+// Traversal record of a leaf item, 64 bytes: a precomputed affine map to "unit triangle" space.
+//   q0 = v0.xyz, eps     q1 = r1.xyz, primitive index bits     q2 = r2.xyz, pair code     q3 = n.xyz, partner
 // r1, r2 are the dual basis of the edges (r1.(v1-v0) = 1, r1.(v2-v0) = 0, ...), n the unit normal,
 // so for a point p: b1 = r1.(p-v0), b2 = r2.(p-v0), distance from the plane = n.(p-v0).
 // eps bounds the rounding error of b1, b2 per unit of coordinate magnitude.
+// Pair code != 0: the item is a parallelogram, this triangle plus the partner primitive, which is this
+// triangle mirrored through the middle of the edge opposite corner k = code & 3.  A point with weights
+// (b0, b1, b2) here has, in the mirror image, weight c_m = 1 - b_m for m != k and c_k = -b_k on the image
+// of corner m; the partner's own corners 1 and 2 are the images of corners (code >> 2) & 3 and
+// (code >> 4) & 3.
 constexpr int kTriWords = 4;
 
 // Fast ray/triangle test: solve for t on the plane, evaluate the barycentrics directly.  It decides
@@ -129,19 +134,46 @@ PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, 
   const float slack = 9.5367431640625e-7f * (rmag + fabsf(t));
   if (!(t + slack > tmin) || !(t - slack < hit.t)) return 0;
   const f3 r1 = ldq(q1), r2 = ldq(q2);
-  const float b1 = __builtin_fmaf(t, shear_dot(r1, d), shear_dot(r1, A));
-  const float b2 = __builtin_fmaf(t, shear_dot(r2, d), shear_dot(r2, A));
+  float b1 = __builtin_fmaf(t, shear_dot(r1, d), shear_dot(r1, A));
+  float b2 = __builtin_fmaf(t, shear_dot(r2, d), shear_dot(r2, A));
   const float b0 = 1.0f - b1 - b2;
   const float eps = q0.w * (rmag + fabsf(t));
-  const float lo = fminf(fminf(b0, b1), b2);
+  float lo = fminf(fminf(b0, b1), b2);
+  uint32_t prim = f2u(q1.w);
+  const uint32_t code = f2u(q2.w);
+  if (code != 0u && lo < -eps) {  // clearly outside this half of a parallelogram: the point's weights in the other
+    const uint32_t k = code & 3u, s1 = (code >> 2) & 3u, s2 = (code >> 4) & 3u;
+    const float c0 = k == 0u ? -b0 : 1.0f - b0;
+    const float c1 = k == 1u ? -b1 : 1.0f - b1;
+    const float c2 = k == 2u ? -b2 : 1.0f - b2;
+    lo = fminf(fminf(c0, c1), c2);
+    b1 = s1 == 0u ? c0 : (s1 == 1u ? c1 : c2);
+    b2 = s2 == 0u ? c0 : (s2 == 1u ? c1 : c2);
+    prim = f2u(q3.w);
+  }
   if (!(lo >= -eps)) return 0;
   if (lo <= eps || t - slack <= tmin) return 2;
   if (!(t < hit.t)) return 0;
   hit.t = t;
   hit.b1 = b1;
   hit.b2 = b2;
-  hit.prim = (int)f2u(q1.w);
+  hit.prim = (int)prim;
   return 1;
+}
+
+// The undecided case of fast_triangle: the watertight test on the original vertices of the item's
+// triangle(s) decides.  Testing a triangle the point is not near costs time only.
+PT_HD bool watertight_item(const SceneView& sc, const q4& q1, const q4& q2, const q4& q3, f3 o, f3 d, float tmin, Hit& hit) {
+  const RayShear rs = make_shear(d);
+  const int prim = (int)f2u(q1.w);
+  const q4* rec = reinterpret_cast<const q4*>(sc.shade + prim);
+  bool found = intersect_triangle(rs, o, ldv(rec[0]), ldv(rec[1]), ldv(rec[2]), tmin, prim, hit);
+  if (f2u(q2.w) != 0u) {
+    const int partner = (int)f2u(q3.w);
+    const q4* rec2 = reinterpret_cast<const q4*>(sc.shade + partner);
+    found |= intersect_triangle(rs, o, ldv(rec2[0]), ldv(rec2[1]), ldv(rec2[2]), tmin, partner, hit);
+  }
+  return found;
 }
 
 PT_HD float safe_inv(float d) {
@@ -268,9 +300,7 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
       int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, tmin, hit);
       if (res == 2) {  // rare: within rounding of an edge -- the watertight test on the original vertices decides
         PT_PROF(PF_FALLBACK);
-        const int prim = (int)f2u(q1.w);
-        const q4* rec = reinterpret_cast<const q4*>(sc.shade + prim);
-        res = intersect_triangle(make_shear(d), o, ldv(rec[0]), ldv(rec[1]), ldv(rec[2]), tmin, prim, hit) ? 1 : 0;
+        res = watertight_item(sc, q1, q2, q3, o, d, tmin, hit) ? 1 : 0;
       }
       if (res == 1 && any_hit) return hit;
     }
@@ -350,11 +380,7 @@ struct TraceState {
     const q4* tp = sc.tris + (uint32_t)kTriWords * (tg.base + (uint32_t)ti);
     const q4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
     int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, tmin, hit);
-    if (res == 2) {
-      const int prim = (int)f2u(q1.w);
-      const q4* rec = reinterpret_cast<const q4*>(sc.shade + prim);
-      res = intersect_triangle(make_shear(d), o, ldv(rec[0]), ldv(rec[1]), ldv(rec[2]), tmin, prim, hit) ? 1 : 0;
-    }
+    if (res == 2) res = watertight_item(sc, q1, q2, q3, o, d, tmin, hit) ? 1 : 0;
     return res == 1 && any_hit;
   }
 };

@@ -155,7 +155,7 @@ __device__ __forceinline__ TrainRec train_rec(const TrainVertex& tv) {
   r.position[0] = tv.P.x; r.position[1] = tv.P.y; r.position[2] = tv.P.z;
   r.dir_in[0] = tv.dir_in.x; r.dir_in[1] = tv.dir_in.y; r.dir_in[2] = tv.dir_in.z;
   r.contrib[0] = tv.T_in.x; r.contrib[1] = tv.T_in.y; r.contrib[2] = tv.T_in.z;
-  r.is_delta = 0u;
+  r.is_delta = train_digest(r);  // flag bit 0 = 0: only non-delta vertices are captured
   return r;
 }
 // Training capture (optix_device.cu:431-441).  The reference appends every non-delta vertex to a ring
@@ -164,7 +164,9 @@ __device__ __forceinline__ TrainRec train_rec(const TrainVertex& tv) {
 // made the fused kernel 2.7x slower).  Here a vertex goes to the ring slot its own random state hashes
 // to -- what survives is a uniform random subset of the render's vertices instead of whichever were
 // appended last -- and the number of vertices is only counted (per lane, summed when the kernel ends).
-// Never-written slots keep the marker the ring is cleared to (is_delta == kTrainEmpty) and are dropped
+// Two vertices that hash to one slot at the same moment may interleave their stores; the digest in
+// is_delta lets the host tell.  Never-written slots keep the marker the ring is cleared to
+// (is_delta == kTrainEmpty) and are dropped
 // when the host maps the ring.
 __device__ __forceinline__ void capture_train(const RenderParams& p, const TrainVertex& tv, uint64_t seed, uint32_t slot,
                                               uint32_t& captured) {
@@ -396,7 +398,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
     // Small scenes: stage nodes, triangles and shading records in LDS behind the traversal
     // stacks, so the divergent 16-byte gathers of traversal and shading never leave the CU.
     u4* dst = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
-    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_tris * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
+    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_items * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
     const u4* src_n = reinterpret_cast<const u4*>(p.scene.nodes);
     const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
     const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
   u4* lds_free = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
   if (LDS_SCENE) {
     u4* dst = lds_free;
-    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_tris * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
+    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_items * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
     const u4* src_n = reinterpret_cast<const u4*>(p.scene.nodes);
     const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
     const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
@@ -810,7 +812,7 @@ void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
-  const size_t scene_bytes = (size_t)p.scene_nodes * 80u + (size_t)p.scene.num_tris * (16u * kTriWords + 96u);
+  const size_t scene_bytes = (size_t)p.scene_nodes * 80u + (size_t)p.scene.num_items * (16u * kTriWords) + (size_t)p.scene.num_tris * 96u;
   const bool lds_scene = p.scene_in_lds && scene_bytes <= 24u * 1024u;
   size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
   const bool guided = p.guiding || p.train;

@@ -188,6 +188,21 @@ struct GuideRegion { float bmin[3]; float bmax[3]; uint32_t lobe_ofs, lobe_num; 
 struct GuideLobe { float mu[3]; float kappa; float weight; float rgb[3]; };
 // optix/guiding_gpu.cuh:24-29
 struct TrainRec { float position[3]; float dir_in[3]; float contrib[3]; uint32_t is_delta; };
+// Ring slots are overwritten without synchronisation, so two vertices written to one slot at the same
+// moment can leave a mix of both.  A record in the ring therefore carries, in bits 1..31 of is_delta, a
+// digest of its nine payload words (bit 0 is the flag itself); the host drops records whose digest does
+// not match.  The digest word of a captured record has bit 0 clear, so it never equals the "never
+// written" marker 0xffffffff.
+PT_HD uint32_t train_digest(const TrainRec& r) {
+  const float w[9] = {r.position[0], r.position[1], r.position[2], r.dir_in[0], r.dir_in[1], r.dir_in[2],
+                      r.contrib[0],  r.contrib[1],  r.contrib[2]};
+  uint32_t h = 0x9E3779B9u;
+  for (int k = 0; k < 9; ++k) {
+    h = (h ^ f2u(w[k])) * 0x85EBCA6Bu;
+    h ^= h >> 15;
+  }
+  return h << 1;
+}
 
 // Device view of the guiding field (optix/guiding_gpu.cuh:18-22).
 struct GuideView {
@@ -201,11 +216,13 @@ struct GuideView {
 
 struct SceneView {
   const BvhNode* nodes;
-  // 4 x q4 per triangle in BVH leaf order (see TriRecord in pt_bvh.h): v0 and the rows that map
-  // (p - v0) to the barycentrics of v1, v2 and to the distance from the plane
+  // 4 x q4 per leaf item (a triangle, or two forming a parallelogram) in BVH leaf order (see the record
+  // layout in pt_bvh.h): v0 and the rows that map (p - v0) to the barycentrics of v1, v2 and to the distance
+  // from the plane
   const q4* tris;
   const ShadeRec* shade;     // per primitive
-  uint32_t num_tris;
+  uint32_t num_tris;         // primitives (shade records)
+  uint32_t num_items;        // traversal records
   float vmag;                // largest |coordinate| of any vertex (error bound of the fast triangle test)
   // rectangle light used for next-event estimation (optix_wrapper.cpp:842-845)
   float light_pos[3], light_emit[3], light_normal[3], light_half[2];

@@ -164,6 +164,7 @@ void upload_scene(State& s) {
   s.scene.tris = s.d_tris;
   s.scene.shade = s.d_shade;
   s.scene.num_tris = (uint32_t)nt;
+  s.scene.num_items = (uint32_t)bvh.num_items;
   s.scene.vmag = bvh.vmag;
   for (int k = 0; k < 3; ++k) {
     s.scene.light_pos[k] = hs.light_pos[k];
@@ -723,8 +724,14 @@ void guiding_map_train_samples(const TrainSample** samples, uint32_t* count) {
   HIP_CHECK(hipMemcpy(&n, st.d_train_idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
   // vertices land in hashed slots (see capture_train): keep the slots that were written, in ring order
   size_t kept = 0;
-  for (size_t i = 0; i < host.size(); ++i)
-    if (host[i].is_delta != kTrainEmpty) host[kept++] = host[i];
+  for (size_t i = 0; i < host.size(); ++i) {
+    if (host[i].is_delta == kTrainEmpty) continue;
+    TrainRec rec;
+    memcpy(&rec, &host[i], sizeof(rec));
+    if ((rec.is_delta & ~1u) != train_digest(rec)) continue;  // two vertices were written here at once
+    host[i].is_delta &= 1u;
+    host[kept++] = host[i];
+  }
   if (samples) *samples = host.data();
   // never report more than were captured or than the ring holds (the reference reports the raw counter)
   if (count) *count = (uint32_t)std::min<size_t>(kept, std::min(n, st.train_capacity));
@@ -901,6 +908,10 @@ void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* i
   g_scene = make_from_triangles(vertices, n_vertices, indices, n_triangles, materials11);
   g_scene_init = true;
   g_scene_version++;
+}
+void pt_set_bvh_pairing(int on) {
+  bvh_set_pairing(on);
+  g_scene_version++;  // the next render rebuilds the tree
 }
 void pt_scene_info(int* n_triangles, int* n_bvh_nodes, int* bvh_depth, size_t* bvh_bytes) {
   State& s = ensure_handle(g_last_w > 0 ? g_last_w : 16, g_last_h > 0 ? g_last_h : 16);

@@ -104,6 +104,7 @@ SIGNATURES = {
     "pt_scene_cornell": (None, []),
     "pt_scene_synthetic": (None, [C.c_uint32, C.c_int, C.c_int]),
     "pt_scene_triangles": (None, [_fp, C.c_int, _u32p, C.c_int, _fp]),
+    "pt_set_bvh_pairing": (None, [C.c_int]),
     "pt_scene_info": (None, [_ip, _ip, _ip, C.POINTER(C.c_size_t)]),
     "pt_scene_get": (None, [_fp, _u32p, _fp, _fp]),
     "pt_dbg_pcg": (C.c_int, [C.c_uint64, C.c_int, _u32p, _fp]),

@@ -35,6 +35,85 @@ def awkward_scene():
     return np.array(verts, np.float32), np.array(idx, np.uint32), centre, rng
 
 
+def quad_scene():
+    """Parallelograms as two triangles each, in every combination of diagonal, winding and corner order, with
+    shared or duplicated vertices, near the origin and 40 units away; plus pairs that only look like quads
+    (trapezoids, kinked quads, a corner moved off the parallelogram) and single triangles in between.
+    Returns (V, I, centre, rng, n_quads): the first 2*n_quads triangles are the true parallelograms."""
+    rng = np.random.default_rng(23)
+    verts, idx = [], []
+
+    def tri_pair(corners, diagonal, rot_a, rot_b, flip_a, flip_b, share):
+        p0, p1, p2, p3 = corners
+        a, b = ([0, 1, 2], [0, 2, 3]) if diagonal == 0 else ([0, 1, 3], [1, 2, 3])
+        a = a[rot_a:] + a[:rot_a]
+        b = b[rot_b:] + b[:rot_b]
+        if flip_a:
+            a = a[::-1]
+        if flip_b:
+            b = b[::-1]
+        base = len(verts)
+        if share:
+            verts.extend([p0, p1, p2, p3])
+            idx.append([base + k for k in a])
+            idx.append([base + k for k in b])
+        else:
+            verts.extend([corners[k] for k in a] + [corners[k] for k in b])
+            idx.append([base, base + 1, base + 2])
+            idx.append([base + 3, base + 4, base + 5])
+
+    centre = np.array([40.0, -25.0, 10.0])
+    n_quads = 0
+    for where in (np.zeros(3), centre):
+        for diagonal in (0, 1):
+            for rot_a in range(3):
+                for rot_b in range(3):
+                    for flips in range(4):
+                        p0 = (where + rng.uniform(-0.5, 0.5, 3)).astype(np.float32)
+                        e1 = (rng.normal(size=3) * 0.3).astype(np.float32)
+                        e2 = (rng.normal(size=3) * 0.3).astype(np.float32)
+                        p1 = p0 + e1
+                        p3 = p0 + e2
+                        p2 = p1 + e2  # float32 sums: the fourth corner is off by the rounding of the coordinates
+                        tri_pair([p0, p1, p2, p3], diagonal, rot_a, rot_b, flips & 1, flips >> 1, (rot_a + rot_b) & 1)
+                        n_quads += 1
+    for k in range(60):  # look-alikes that must stay two triangles
+        p0 = centre + rng.uniform(-0.5, 0.5, 3)
+        e1, e2 = rng.normal(size=3) * 0.3, rng.normal(size=3) * 0.3
+        kind = k % 3
+        if kind == 0:    # trapezoid: planar, not a parallelogram
+            corners = [p0, p0 + e1, p0 + 0.6 * e1 + e2, p0 + e2]
+        elif kind == 1:  # kinked: fourth corner out of the plane
+            corners = [p0, p0 + e1, p0 + e1 + e2 + 0.05 * np.cross(e1, e2) / np.linalg.norm(np.cross(e1, e2)), p0 + e2]
+        else:            # parallelogram with one corner moved by 1e-4
+            corners = [p0, p0 + e1, p0 + e1 + e2 + 1e-4, p0 + e2]
+        tri_pair([np.asarray(c, np.float32) for c in corners], k & 1, 0, 0, 0, 0, 1)
+    for _ in range(40):  # singles
+        p = centre + rng.uniform(-0.6, 0.6, 3)
+        base = len(verts)
+        verts.extend([p, p + rng.normal(size=3) * 0.3, p + rng.normal(size=3) * 0.3])
+        idx.append([base, base + 1, base + 2])
+    return np.array(verts, np.float32), np.array(idx, np.uint32), centre, rng, n_quads
+
+
+def quad_rays(V, I, rng, n=8000):
+    """Rays from around either cluster aimed at points of random triangles: interiors, the shared diagonals,
+    outer edges and corners."""
+    tri = rng.integers(0, len(I), n)
+    w = rng.dirichlet([0.4, 0.4, 0.4], n)
+    k = n // 4
+    w[:k] = 0.0  # exactly on an edge: two corners share the weight
+    e = rng.integers(0, 3, k)
+    u = rng.uniform(0, 1, k)
+    w[np.arange(k), e] = u
+    w[np.arange(k), (e + 1) % 3] = 1 - u
+    target = V[I[tri, 0]] * w[:, :1] + V[I[tri, 1]] * w[:, 1:2] + V[I[tri, 2]] * w[:, 2:3]
+    o = (target + rng.normal(size=(n, 3)) * 1.5).astype(np.float32)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
 def awkward_rays(V, I, centre, rng):
     n = 6000
     o = (centre + rng.normal(size=(n, 3)) * 1.5).astype(np.float32)
@@ -88,5 +167,8 @@ def check_against_float64(V, I, o, d, prim, t, b1, b2):
     well_defined = margin[prim[hit]] < 0.5  # not the (nearly) collinear ones, whose plane is rounding noise
     assert (dt < t_tol)[well_defined].all()  # distance of the reported triangle
     assert hit.mean() > 0.5
+    # barycentrics of the reported triangle (corner order of that triangle, not of a neighbour)
+    db = np.maximum(np.abs(b1[hit] - bb1[rows[hit], prim[hit]]), np.abs(b2[hit] - bb2[rows[hit], prim[hit]]))
+    assert (db < margin[prim[hit]] + 1e-4)[well_defined].all()
     assert (b1[hit] >= -1e-3).all() and (b2[hit] >= -1e-3).all() and (b1[hit] + b2[hit] <= 1 + 1e-3).all()
     return definite_miss, strict_miss, t_first, rows

@@ -54,6 +54,7 @@ void finish_scene() {
   g_sv.tris = g_bvh.tris.data();
   g_sv.shade = g_recs.data();
   g_sv.num_tris = (uint32_t)nt;
+  g_sv.num_items = (uint32_t)g_bvh.num_items;
   g_sv.vmag = g_bvh.vmag;
   for (int k = 0; k < 3; ++k) {
     g_sv.light_pos[k] = g_hs.light_pos[k]; g_sv.light_emit[k] = g_hs.light_emit[k]; g_sv.light_normal[k] = g_hs.light_normal[k];
@@ -97,6 +98,9 @@ void hc_scene_get(float* v, uint32_t* idx, float* nrm, float* m11) {
   if (m11) memcpy(m11, g_hs.materials.data(), g_hs.materials.size() * sizeof(Material));
 }
 void hc_set_origin_skip(int on) { g_origin_skip = on; }
+// rebuilds the current scene's tree with or without parallelogram items
+void hc_set_pairing(int on) { bvh_set_pairing(on); ensure(); finish_scene(); }
+int hc_num_items() { ensure(); return g_bvh.num_items; }
 // FNV-1a over the built BVH arrays (nodes, triangle records, home masks)
 unsigned long long hc_bvh_hash() {
   ensure();

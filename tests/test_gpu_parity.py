@@ -219,6 +219,49 @@ def test_awkward_geometry_is_sound(gpu):
         L.pt_scene_cornell()
 
 
+def test_parallelogram_items(gpu):
+    """Quads given as two consecutive triangles are traversed as one item each: right primitive, that
+    primitive's own barycentrics, for every diagonal / winding / corner order (tests/geom_cases.py), and the
+    same render as with one item per triangle."""
+    import geom_cases
+    L = gpu.lib()
+    V, I, centre, rng, n_quads = geom_cases.quad_scene()
+    L.pt_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
+    try:
+        o, d = geom_cases.quad_rays(V, I, rng, 20000)
+        prim, t, b1, b2 = gpu.trace_rays(o, d)
+        info = gpu.scene_info()
+        assert (info["bvh_bytes"] - 80 * info["nodes"]) // 64 == len(I) - n_quads
+        geom_cases.check_against_float64(V, I, o, d, prim, t, b1, b2)
+        L.pt_set_bvh_pairing(0)
+        prim0, t0, b10, b20 = gpu.trace_rays(o, d)
+        info = gpu.scene_info()
+        assert (info["bvh_bytes"] - 80 * info["nodes"]) // 64 == len(I)
+        same = prim == prim0
+        assert same.mean() > 0.98
+        hit = same & (prim >= 0)
+        db = np.maximum(np.abs(b1[hit] - b10[hit]), np.abs(b2[hit] - b20[hit]))
+        assert np.abs(t[hit] - t0[hit]).max() < 2e-3 and db.max() < 5e-3  # grazing rays 40 units out
+        assert np.quantile(np.abs(t[hit] - t0[hit]), 0.999) < 2e-4 and np.quantile(db, 0.999) < 2e-4
+    finally:
+        L.pt_set_bvh_pairing(-1)
+        L.pt_scene_cornell()
+    # the built-in scene (twelve quads) renders the same image with and without pairing
+    w, h, spp = 96, 54, 256
+    imgs, rays = [], []
+    for pairing in (1, 0):
+        L.pt_set_bvh_pairing(pairing)
+        L.pt_set_frame(0)
+        L.pt_reset_ray_counts()
+        imgs.append(gpu.render_rgb(w, h, spp))
+        rays.append(sum(gpu.ray_counts()))
+    L.pt_set_bvh_pairing(-1)
+    assert abs(rays[0] - rays[1]) / rays[1] < 2e-3
+    assert abs(imgs[0].mean() - imgs[1].mean()) / imgs[1].mean() < 0.01
+    close = (np.abs(imgs[0] - imgs[1]) <= 2e-3 + 2e-2 * np.abs(imgs[1])).all(axis=2).mean()
+    assert close > 0.5, close  # most pixels follow the very same paths; the rest are re-drawn
+
+
 def test_watertight_closed_box(gpu):
     """No ray leaving an interior point away from the open front escapes (shared diagonals / edges)."""
     rng = np.random.default_rng(3)

@@ -169,6 +169,39 @@ def test_awkward_geometry_matches_brute_force(hostcheck, oracle):
         hostcheck.hc_scene_cornell()
 
 
+def test_parallelogram_items_give_the_triangles_answers(hostcheck):
+    """Two consecutive triangles that form a parallelogram share one traversal record; the partner is found
+    through the mirrored barycentrics of the first.  Every diagonal / winding / corner-order combination must
+    report the right primitive with that primitive's own barycentrics, look-alikes must not be paired, and
+    the answers must be those of the tree built without pairing."""
+    import geom_cases
+    V, I, centre, rng, n_quads = geom_cases.quad_scene()
+    hostcheck.hc_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
+    try:
+        assert hostcheck.hc_num_items() == len(I) - n_quads  # every true parallelogram, nothing else
+        o, d = geom_cases.quad_rays(V, I, rng)
+        prim, t, b1, b2 = _hc_trace(hostcheck, o, d)
+        geom_cases.check_against_float64(V, I, o, d, prim, t, b1, b2)
+        assert (prim[prim >= 0] % 2 == 1).mean() > 0.3  # second halves are reported as themselves
+        tmax = rng.uniform(0.2, 4.0, len(o)).astype(np.float32)
+        occ, _, _, _ = _hc_trace(hostcheck, o, d, tmax, any_hit=1)
+        hostcheck.hc_set_pairing(0)
+        assert hostcheck.hc_num_items() == len(I)
+        prim0, t0, b10, b20 = _hc_trace(hostcheck, o, d)
+        occ0, _, _, _ = _hc_trace(hostcheck, o, d, tmax, any_hit=1)
+        same = prim == prim0
+        assert same.mean() > 0.98  # rays aimed exactly at shared edges may report either neighbour
+        hit = same & (prim >= 0)
+        db = np.maximum(np.abs(b1[hit] - b10[hit]), np.abs(b2[hit] - b20[hit]))
+        assert np.abs(t[hit] - t0[hit]).max() < 2e-3 and db.max() < 5e-3  # grazing rays 40 units out
+        assert np.quantile(np.abs(t[hit] - t0[hit]), 0.999) < 2e-4 and np.quantile(db, 0.999) < 2e-4
+        assert ((occ >= 0) == (occ0 >= 0)).mean() > 0.999
+    finally:
+        hostcheck.hc_set_pairing(-1)
+        hostcheck.hc_scene_cornell()
+    assert hostcheck.hc_num_items() == 12  # the built-in scene is twelve quads
+
+
 def test_watertight_no_leak_through_shared_edges(hostcheck):
     """Rays aimed exactly at quad diagonals, edges and corners of the closed part of the box
     must hit something (the two triangles of a quad share their diagonal)."""
