@@ -49,9 +49,13 @@ constexpr uint32_t kNoPartner = 0xffffffffu;
 // along a diagonal), which traversal tests with one plane intersection.
 struct Item {
   uint32_t a, b;   // input triangles; b == kNoPartner: single
-  uint32_t code;   // 0x40 | k | sel1 << 2 | sel2 << 4 (see the record layout in pt_bvh.h), 0 for a single
+  // corner orders (2 bits per corner: which input corner comes first, second, third) in which the two halves
+  // of a parallelogram are recorded: a starts at its corner off the shared diagonal, b at its own such corner
+  // followed by the images of a's second and third corner under the half-turn that maps a onto b
+  uint8_t order_a, order_b;
   float delta;     // how far b's own corner is from the exact parallelogram corner (max norm)
 };
+constexpr uint8_t kInputOrder = 0 | (1 << 2) | (2 << 4);
 
 // Triangles A and B share an edge and B's third corner is A's third corner mirrored through the middle of
 // that edge (within rounding of the coordinates).
@@ -84,15 +88,11 @@ bool try_pair(const float* verts, const uint32_t* idx, uint32_t A, uint32_t B, f
   const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
   if (!(nn > 0.0) || !std::isfinite(nn)) return false;
   if (!(delta <= std::ldexp((double)vmag, -21))) return false;
-  // mirroring sends A's corner i to j, j to i and k to B's own corner; weight c_m of the mirrored point
-  // belongs to the image of corner m
-  auto source_of = [&](int w) {  // which c_m is the weight of B's corner w
-    if (w == kb) return k;
-    return in_b[i] == w ? j : i;
-  };
+  // the half-turn about the middle of the shared edge sends A's corner i to j, j to i and k to B's own corner
   item.a = A;
   item.b = B;
-  item.code = 0x40u | (uint32_t)k | ((uint32_t)source_of(1) << 2) | ((uint32_t)source_of(2) << 4);
+  item.order_a = (uint8_t)(k | (i << 2) | (j << 4));
+  item.order_b = (uint8_t)(kb | (in_b[j] << 2) | (in_b[i] << 4));
   item.delta = (float)delta;
   return true;
 }
@@ -425,7 +425,9 @@ struct Emitter {
     const uint32_t* t = b.idx + 3 * (size_t)prim;
     double v[3][3];
     for (int k = 0; k < 3; ++k)
-      for (int c = 0; c < 3; ++c) v[k][c] = (double)b.verts[3 * (size_t)t[k] + c];
+      for (int c = 0; c < 3; ++c) v[k][c] = (double)b.verts[3 * (size_t)t[(item.order_a >> (2 * k)) & 3] + c];
+    out.corner_order[prim] = item.order_a;
+    if (item.b != kNoPartner) out.corner_order[item.b] = item.order_b;
     const double e1[3] = {v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]};
     const double e2[3] = {v[2][0] - v[0][0], v[2][1] - v[0][1], v[2][2] - v[0][2]};
     const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
@@ -444,10 +446,10 @@ struct Emitter {
     const double norm2 = std::fabs(r2[0]) + std::fabs(r2[1]) + std::fabs(r2[2]);
     // 16 ulps of the largest term of the dot products per unit of coordinate magnitude, both rows
     double eps = std::ldexp(norm1 + norm2, -20);
-    if (item.code) {
-      // the partner is tested as A's mirror image: widen the band by what its real corner is off by
+    if (item.b != kNoPartner) {
+      // the partner is tested as this triangle's image: widen the band by what its real corner is off by
       eps += (norm1 + norm2) * (double)item.delta / std::max((double)out.vmag, 1e-30);
-      q[2].w = u2f(item.code);
+      q[2].w = u2f(1u);
       q[3].w = u2f(item.b);
     }
     q[0].w = (float)eps;
@@ -655,7 +657,7 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   std::vector<Item> items;
   items.reserve((size_t)num_tris);
   for (int t = 0; t < num_tris; ++t) {
-    Item item{(uint32_t)t, kNoPartner, 0u, 0.f};
+    Item item{(uint32_t)t, kNoPartner, kInputOrder, kInputOrder, 0.f};
     if (pairing && t + 1 < num_tris && try_pair(vertices, indices, (uint32_t)t, (uint32_t)t + 1u, out.vmag, item)) ++t;
     items.push_back(item);
   }
@@ -703,6 +705,7 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   out.tris.resize(4 * (size_t)num_items);
   out.home_node.assign((size_t)num_tris, 0u);
   out.home_mask.assign((size_t)num_tris, 0u);
+  out.corner_order.assign((size_t)num_tris, kInputOrder);
   Emitter em{b, out, items};
   em.below.assign(b.nodes2.size(), 0u);
   const uint32_t nodes_below_root = em.count_below(root2);

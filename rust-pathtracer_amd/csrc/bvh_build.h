@@ -17,6 +17,10 @@ struct BvhBuildResult {
   // per primitive: the node whose leaf slots hold it, and the bits (offsets in that node's triangle
   // range) of every triangle of that node lying in the same plane, itself included
   std::vector<uint32_t> home_node, home_mask;
+  // per primitive: the order in which its corners are recorded for traversal and shading, 2 bits each
+  // (bits 0-1: the input corner that comes first, ...); 0x24 = as given.  Barycentrics of a hit refer to
+  // this order.
+  std::vector<uint8_t> corner_order;
   int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
   int num_tris = 0;
   int num_items = 0;           // leaf items: single triangles, or two triangles forming a parallelogram

@@ -109,10 +109,9 @@ PT_HD bool intersect_triangle(const RayShear& rs, f3 o, f3 v0, f3 v1, f3 v2, flo
 // so for a point p: b1 = r1.(p-v0), b2 = r2.(p-v0), distance from the plane = n.(p-v0).
 // eps bounds the rounding error of b1, b2 per unit of coordinate magnitude.
 // Pair code != 0: the item is a parallelogram, this triangle plus the partner primitive, which is this
-// triangle mirrored through the middle of the edge opposite corner k = code & 3.  A point with weights
-// (b0, b1, b2) here has, in the mirror image, weight c_m = 1 - b_m for m != k and c_k = -b_k on the image
-// of corner m; the partner's own corners 1 and 2 are the images of corners (code >> 2) & 3 and
-// (code >> 4) & 3.
+// triangle turned by 180 degrees about the middle of the edge v1-v2 (the shared diagonal; v0 is the corner
+// off it).  The partner's shading record lists its corners as (image of v0, image of v1, image of v2), so
+// a point with weights (b0, b1, b2) here and b0 < 0 has weights (-b0, 1 - b1, 1 - b2) there.
 constexpr int kTriWords = 4;
 
 // Fast ray/triangle test: solve for t on the plane, evaluate the barycentrics directly.  It decides
@@ -141,14 +140,10 @@ PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, 
   float lo = fminf(fminf(b0, b1), b2);
   uint32_t prim = f2u(q1.w);
   const uint32_t code = f2u(q2.w);
-  if (code != 0u && lo < -eps) {  // clearly outside this half of a parallelogram: the point's weights in the other
-    const uint32_t k = code & 3u, s1 = (code >> 2) & 3u, s2 = (code >> 4) & 3u;
-    const float c0 = k == 0u ? -b0 : 1.0f - b0;
-    const float c1 = k == 1u ? -b1 : 1.0f - b1;
-    const float c2 = k == 2u ? -b2 : 1.0f - b2;
-    lo = fminf(fminf(c0, c1), c2);
-    b1 = s1 == 0u ? c0 : (s1 == 1u ? c1 : c2);
-    b2 = s2 == 0u ? c0 : (s2 == 1u ? c1 : c2);
+  if (code != 0u && b0 < -eps) {  // clearly beyond the diagonal of a parallelogram: the point's weights in the other half
+    b1 = 1.0f - b1;
+    b2 = 1.0f - b2;
+    lo = fminf(fminf(-b0, b1), b2);
     prim = f2u(q3.w);
   }
   if (!(lo >= -eps)) return 0;
@@ -174,6 +169,22 @@ PT_HD bool watertight_item(const SceneView& sc, const q4& q1, const q4& q2, cons
     found |= intersect_triangle(rs, o, ldv(rec2[0]), ldv(rec2[1]), ldv(rec2[2]), tmin, partner, hit);
   }
   return found;
+}
+
+// Hits carry barycentrics in the corner order of the shading record (ShadeRec::corner_order); these two
+// convert to and from the order in which the scene's triangles were given.
+PT_HD void to_input_order(uint32_t corner_order, float& b1, float& b2) {
+  float w[3];
+  const float b[3] = {1.0f - b1 - b2, b1, b2};
+  for (int m = 0; m < 3; ++m) w[(corner_order >> (2 * m)) & 3u] = b[m];
+  b1 = w[1];
+  b2 = w[2];
+}
+PT_HD void to_record_order(uint32_t corner_order, float& b1, float& b2) {
+  const float w[3] = {1.0f - b1 - b2, b1, b2};
+  const float r1 = w[(corner_order >> 2) & 3u], r2 = w[(corner_order >> 4) & 3u];
+  b1 = r1;
+  b2 = r2;
 }
 
 PT_HD float safe_inv(float d) {

@@ -919,7 +919,9 @@ __global__ void __launch_bounds__(256) k_trace_rays(SceneView sc, int stack_dept
       prim[i] = h.prim >= 0 ? 1 : 0;
     } else {
       prim[i] = h.prim;
-      t[i] = h.t; b1[i] = h.b1; b2[i] = h.b2;
+      float r1 = h.b1, r2 = h.b2;
+      if (h.prim >= 0) to_input_order(sc.shade[h.prim].corner_order, r1, r2);
+      t[i] = h.t; b1[i] = r1; b2[i] = r2;
     }
   }
 }
@@ -939,7 +941,8 @@ __global__ void __launch_bounds__(256) k_dbg_shade(SceneView sc, GuideView gv, i
     const uint32_t dim = r.rng_dim < 2 ? (uint32_t)r.rng_dim : 2u;
     ps.flags = ((uint32_t)r.depth & kDepthMask) | (dim << kDimShift) | (r.prev_pdf_valid ? kPrevValid : 0u) | kAlive;
     const RandCtx rc{r.px, r.py, r.sample, frame};
-    const Hit h{prim[i], 0.f, b1[i], b2[i]};
+    Hit h{prim[i], 0.f, b1[i], b2[i]};  // barycentrics arrive in the order the triangle was given
+    if (h.prim >= 0) to_record_order(sc.shade[h.prim].corner_order, h.b1, h.b2);
     ShadowRay sr;
     const ShadeParams sp{frame, max_depth, guiding};
     TrainVertex tv;

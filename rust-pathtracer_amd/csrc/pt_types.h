@@ -179,7 +179,7 @@ struct alignas(16) ShadeRec {
   float v2[3]; float transmission;
   float ng[3]; uint32_t home_node;   // BVH node whose leaf slots hold this primitive
   float base[3]; uint32_t home_mask;  // triangles of that node in this primitive's plane (bit = offset in the node)
-  float emission[3]; float pad2;
+  float emission[3]; uint32_t corner_order;  // input corner held by v0 / v1 / v2, 2 bits each (0x24: as given)
 };
 static_assert(sizeof(ShadeRec) == 96, "ShadeRec must be 96 bytes");
 

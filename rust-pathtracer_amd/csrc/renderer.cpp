@@ -139,10 +139,12 @@ void upload_scene(State& s) {
   for (int i = 0; i < nt; ++i) {
     ShadeRec& r = recs[(size_t)i];
     const Material& m = hs.materials[(size_t)i];
+    const uint32_t co = bvh.corner_order[(size_t)i];  // corners in the order the traversal records use
+    r.corner_order = co;
     for (int k = 0; k < 3; ++k) {
-      r.v0[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + 0] + k];
-      r.v1[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + 1] + k];
-      r.v2[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + 2] + k];
+      r.v0[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + (co & 3u)] + k];
+      r.v1[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + ((co >> 2) & 3u)] + k];
+      r.v2[k] = hs.vertices[3 * (size_t)hs.indices[3 * (size_t)i + ((co >> 4) & 3u)] + k];
       r.base[k] = m.base[k];
       r.emission[k] = m.emission[k];
     }

@@ -36,10 +36,12 @@ void finish_scene() {
   for (int i = 0; i < nt; ++i) {
     ShadeRec& r = g_recs[(size_t)i];
     const Material& m = g_hs.materials[(size_t)i];
+    const uint32_t co = g_bvh.corner_order[(size_t)i];
+    r.corner_order = co;
     for (int k = 0; k < 3; ++k) {
-      r.v0[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + 0] + k];
-      r.v1[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + 1] + k];
-      r.v2[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + 2] + k];
+      r.v0[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + (co & 3u)] + k];
+      r.v1[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + ((co >> 2) & 3u)] + k];
+      r.v2[k] = g_hs.vertices[3 * (size_t)g_hs.indices[3 * (size_t)i + ((co >> 4) & 3u)] + k];
       r.base[k] = m.base[k];
       r.emission[k] = m.emission[k];
     }
@@ -125,7 +127,10 @@ void hc_trace_rays(int n, const float* o, const float* d, const float* tmin, con
     Hit h = trace_ray(g_sv, mk3(o[3*i], o[3*i+1], o[3*i+2]), mk3(d[3*i], d[3*i+1], d[3*i+2]), tmin[i], tmax[i],
                       any_hit != 0, st, 64);
     if (any_hit) { prim[i] = h.prim >= 0 ? 1 : 0; }
-    else { prim[i] = h.prim; t[i] = h.t; b1[i] = h.b1; b2[i] = h.b2; }
+    else {
+      if (h.prim >= 0) to_input_order(g_sv.shade[h.prim].corner_order, h.b1, h.b2);
+      prim[i] = h.prim; t[i] = h.t; b1[i] = h.b1; b2[i] = h.b2;
+    }
   }
 }
 
@@ -157,6 +162,7 @@ void hc_shade(int n, HcRec* recs, const int* prim, const float* b1, const float*
     ps.flags = ((uint32_t)r.depth & kDepthMask) | (dim << kDimShift) | (r.prev_pdf_valid ? kPrevValid : 0u) | kAlive;
     RandCtx rc{r.px, r.py, r.sample, frame};
     Hit h{prim[i], 0.f, b1[i], b2[i]};
+    if (h.prim >= 0) to_record_order(g_sv.shade[h.prim].corner_order, h.b1, h.b2);
     ShadowRay sr;
     ShadeParams sp{frame, max_depth, g_guiding};
     TrainVertex tv;
