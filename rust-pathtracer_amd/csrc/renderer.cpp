@@ -382,7 +382,7 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
 struct RenderLoop {
   State& s;
   RenderParams p;
-  LaunchCfg cfg;
+  LaunchCfg cfg, cfg_fused;
   bool fused;
   bool tail_fused = false;
   uint64_t iter = 0;
@@ -390,10 +390,17 @@ struct RenderLoop {
   RenderLoop(State& st, const RenderParams& params) : s(st), p(params) {
     const size_t slots = (size_t)p.npx * (size_t)p.chunks;
     cfg.threads = 256;
-    static const int blocks_per_cu = getenv("PT_BLOCKS_PER_CU") ? atoi(getenv("PT_BLOCKS_PER_CU")) : 16;
-    cfg.blocks = (int)std::min<size_t>((slots + 255) / 256, (size_t)s.num_cus * (size_t)std::max(blocks_per_cu, 1));
-    cfg.blocks = std::max(cfg.blocks, 1);
+    // grid-stride kernels: several blocks per resident slot even out the tail.  The staged kernels hand
+    // every wave one contiguous range of the queue and do better with fewer, longer ranges.
+    static const int env_blocks = getenv("PT_BLOCKS_PER_CU") ? atoi(getenv("PT_BLOCKS_PER_CU")) : 0;
+    auto blocks_for = [&](int per_cu) {
+      const int bpc = std::max(env_blocks > 0 ? env_blocks : per_cu, 1);
+      return std::max((int)std::min<size_t>((slots + 255) / 256, (size_t)s.num_cus * (size_t)bpc), 1);
+    };
+    cfg.blocks = blocks_for(16);
     cfg.stream = s.stream;
+    cfg_fused = cfg;
+    cfg_fused.blocks = blocks_for(32);
     // Small scenes are instruction-bound: keep paths in registers (fused).  Scenes whose BVH lives in
     // HBM are latency-bound: the lean staged kernels run at twice the occupancy and win.
     const int chosen = pipeline();
@@ -433,7 +440,7 @@ struct RenderLoop {
           // compact the slot queue on the last launch of a batch only: finished slots are rare
           const int compact = (b == iters_per_batch - 1) ? 1 : 0;
           Timer t(s, PT_K_BOUNCE, timed, 0);
-          launch_bounce(p, qin, std::max(fused_bounces, 1), compact, cfg);
+          launch_bounce(p, qin, std::max(fused_bounces, 1), compact, cfg_fused);
           if (compact) qin ^= 1;
           continue;
         }
