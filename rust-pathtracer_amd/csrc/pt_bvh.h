@@ -250,6 +250,69 @@ PT_HD uint32_t intersect_children(const NodeWords& n, const RayBox& rb, float tm
   return mask;
 }
 
+// Nodes of a scene small enough to live in LDS are kept there unpacked, 256 bytes each (16 x u4), so that a
+// visit does not spend half its instructions on decoding what is the same for every lane:
+//   u4[0] = grid origin x y z (float bits), imask | first leaf item << 8
+//   u4[1] = grid step x y z (float bits: 2^e), first internal child
+//   u4[2..3]  = per slot, the traversal bits the child contributes when its box is hit (leaf: its item bits;
+//               internal: bit 24 + slot, moved to 24 + (slot ^ octinv) after the test)
+//   u4[4..15] = the quantised bounds as floats, 8 slots each: lo x, lo y, lo z, hi x, hi y, hi z
+// The box arithmetic is that of intersect_children, operation for operation, so both forms agree bit for bit.
+constexpr uint32_t kWideNodeWords = 16;
+
+PT_HD void unpack_node_slot(const BvhNode& nd, int j, uint32_t* w) {
+  w[16 + j] = f2u((float)nd.qlox[j]); w[24 + j] = f2u((float)nd.qloy[j]); w[32 + j] = f2u((float)nd.qloz[j]);
+  w[40 + j] = f2u((float)nd.qhix[j]); w[48 + j] = f2u((float)nd.qhiy[j]); w[56 + j] = f2u((float)nd.qhiz[j]);
+  const uint32_t meta = nd.meta[j];
+  const bool inner = ((meta & (meta << 1)) & 0x10u) != 0u;
+  w[8 + j] = inner ? 1u << (meta & 0x1fu) : ((meta >> 5) & 7u) << (meta & 0x1fu);
+  if (j == 0) {
+    w[0] = f2u(nd.px); w[1] = f2u(nd.py); w[2] = f2u(nd.pz);
+    w[3] = (uint32_t)nd.imask | (nd.tri_base << 8);
+    w[4] = (uint32_t)nd.ex << 23; w[5] = (uint32_t)nd.ey << 23; w[6] = (uint32_t)nd.ez << 23;
+    w[7] = nd.child_base;
+  }
+}
+
+PT_HD uint32_t intersect_children_wide(const u4* n, const RayBox& rb, float tmin, float tmax) {
+  const u4 ha = n[0], hb = n[1];
+  const float sx = u2f(hb.x) * rb.idir.x, sy = u2f(hb.y) * rb.idir.y, sz = u2f(hb.z) * rb.idir.z;
+  const float bx = (u2f(ha.x) - rb.o.x) * rb.idir.x;
+  const float by = (u2f(ha.y) - rb.o.y) * rb.idir.y;
+  const float bz = (u2f(ha.z) - rb.o.z) * rb.idir.z;
+  const bool px = (rb.octinv & 4u) != 0u, py = (rb.octinv & 2u) != 0u, pz = (rb.octinv & 1u) != 0u;
+  const u4* nx = n + (px ? 4 : 10), *fx = n + (px ? 10 : 4);
+  const u4* ny = n + (py ? 6 : 12), *fy = n + (py ? 12 : 6);
+  const u4* nz = n + (pz ? 8 : 14), *fz = n + (pz ? 14 : 8);
+  uint32_t mask = 0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const u4 w = n[2 + half];
+    const u4 ax = nx[half], bxw = fx[half], ay = ny[half], byw = fy[half], az = nz[half], bzw = fz[half];
+    const uint32_t wj[4] = {w.x, w.y, w.z, w.w};
+    const uint32_t nxj[4] = {ax.x, ax.y, ax.z, ax.w}, fxj[4] = {bxw.x, bxw.y, bxw.z, bxw.w};
+    const uint32_t nyj[4] = {ay.x, ay.y, ay.z, ay.w}, fyj[4] = {byw.x, byw.y, byw.z, byw.w};
+    const uint32_t nzj[4] = {az.x, az.y, az.z, az.w}, fzj[4] = {bzw.x, bzw.y, bzw.z, bzw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float tnx = u2f(nxj[j]) * sx + bx, tfx = u2f(fxj[j]) * sx + bx;
+      const float tny = u2f(nyj[j]) * sy + by, tfy = u2f(fyj[j]) * sy + by;
+      const float tnz = u2f(nzj[j]) * sz + bz, tfz = u2f(fzj[j]) * sz + bz;
+      const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
+      if (tn <= tf) mask |= wj[j];
+    }
+  }
+  if (mask & 0xff000000u) {  // internal children: slot s is visited in the order of s ^ octinv
+    uint32_t top = mask >> 24;
+    if (px) top = ((top & 0xf0u) >> 4) | ((top & 0x0fu) << 4);
+    if (py) top = ((top & 0xccu) >> 2) | ((top & 0x33u) << 2);
+    if (pz) top = ((top & 0xaau) >> 1) | ((top & 0x55u) << 1);
+    mask = (mask & 0x00ffffffu) | (top << 24);
+  }
+  return mask;
+}
+
 // Stack policies: push(level, entry) / pop(level).
 struct LocalStack {
   StackEntry e[64];
@@ -290,11 +353,21 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
       const uint32_t slot = (uint32_t)(bit - 24) ^ rb.octinv;
       const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot));
       const uint32_t node_index = cur.base + rel;
-      const NodeWords n = load_node(sc.nodes, node_index);
-      const uint32_t hm = intersect_children(n, rb, tmin, hit.t);
-      cur.base = n.q[1].x;
-      cur.bits = (hm & 0xff000000u) | (n.q[0].w >> 24);
-      tg.base = n.q[1].y;
+      uint32_t hm;
+      if (sc.wide) {
+        const u4* n = sc.wide + kWideNodeWords * node_index;
+        hm = intersect_children_wide(n, rb, tmin, hit.t);
+        const uint32_t packed = n[0].w;
+        cur.base = n[1].w;
+        cur.bits = (hm & 0xff000000u) | (packed & 0xffu);
+        tg.base = packed >> 8;
+      } else {
+        const NodeWords n = load_node(sc.nodes, node_index);
+        hm = intersect_children(n, rb, tmin, hit.t);
+        cur.base = n.q[1].x;
+        cur.bits = (hm & 0xff000000u) | (n.q[0].w >> 24);
+        tg.base = n.q[1].y;
+      }
       tg.bits = hm & 0x00ffffffu;
       if (node_index == home_node) tg.bits &= ~home_mask;
     } else {

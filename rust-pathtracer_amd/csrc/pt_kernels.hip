@@ -387,6 +387,25 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 3
 #endif
+// Small scenes: nodes (unpacked, pt_bvh.h), item records and shading records are staged in LDS behind the
+// traversal stacks, so the divergent 16-byte gathers of traversal and shading never leave the CU.  Returns
+// the first free u4 after the staged scene.
+__device__ __forceinline__ u4* stage_scene(const RenderParams& p, u4* dst, SceneView& sc) {
+  const uint32_t n_nodes16 = p.scene_nodes * kWideNodeWords, n_tris16 = p.scene.num_items * (uint32_t)kTriWords,
+                 n_shade16 = p.scene.num_tris * 6u;
+  const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
+  const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
+  for (uint32_t k = threadIdx.x; k < p.scene_nodes * 8u; k += blockDim.x)
+    unpack_node_slot(p.scene.nodes[k >> 3], (int)(k & 7u), reinterpret_cast<uint32_t*>(dst + kWideNodeWords * (k >> 3)));
+  for (uint32_t k = threadIdx.x; k < n_tris16; k += blockDim.x) dst[n_nodes16 + k] = src_t[k];
+  for (uint32_t k = threadIdx.x; k < n_shade16; k += blockDim.x) dst[n_nodes16 + n_tris16 + k] = src_s[k];
+  __syncthreads();
+  sc.wide = dst;
+  sc.tris = reinterpret_cast<const q4*>(dst + n_nodes16);
+  sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
+  return dst + n_nodes16 + n_tris16 + n_shade16;
+}
+
 template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
 __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p, int qin, int bounces, int compact) {
   const uint32_t n = p.counters[qin];
@@ -395,20 +414,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
   LdsStack st = lds_stack();
   SceneView sc = p.scene;
   if (LDS_SCENE) {
-    // Small scenes: stage nodes, triangles and shading records in LDS behind the traversal
-    // stacks, so the divergent 16-byte gathers of traversal and shading never leave the CU.
     u4* dst = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
-    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_items * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
-    const u4* src_n = reinterpret_cast<const u4*>(p.scene.nodes);
-    const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
-    const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
-    for (uint32_t k = threadIdx.x; k < n_nodes16; k += blockDim.x) dst[k] = src_n[k];
-    for (uint32_t k = threadIdx.x; k < n_tris16; k += blockDim.x) dst[n_nodes16 + k] = src_t[k];
-    for (uint32_t k = threadIdx.x; k < n_shade16; k += blockDim.x) dst[n_nodes16 + n_tris16 + k] = src_s[k];
-    __syncthreads();
-    sc.nodes = reinterpret_cast<const BvhNode*>(dst);
-    sc.tris = reinterpret_cast<const q4*>(dst + n_nodes16);
-    sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
+    stage_scene(p, dst, sc);
+    __builtin_assume(sc.wide != nullptr);
+  } else {
+    sc.wide = nullptr;
   }
 #ifdef PT_PROFILE
   if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
@@ -511,19 +521,10 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
   SceneView sc = p.scene;
   u4* lds_free = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
   if (LDS_SCENE) {
-    u4* dst = lds_free;
-    const uint32_t n_nodes16 = p.scene_nodes * 5u, n_tris16 = p.scene.num_items * (uint32_t)kTriWords, n_shade16 = p.scene.num_tris * 6u;
-    const u4* src_n = reinterpret_cast<const u4*>(p.scene.nodes);
-    const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
-    const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
-    for (uint32_t k = threadIdx.x; k < n_nodes16; k += blockDim.x) dst[k] = src_n[k];
-    for (uint32_t k = threadIdx.x; k < n_tris16; k += blockDim.x) dst[n_nodes16 + k] = src_t[k];
-    for (uint32_t k = threadIdx.x; k < n_shade16; k += blockDim.x) dst[n_nodes16 + n_tris16 + k] = src_s[k];
-    __syncthreads();
-    sc.nodes = reinterpret_cast<const BvhNode*>(dst);
-    sc.tris = reinterpret_cast<const q4*>(dst + n_nodes16);
-    sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
-    lds_free = dst + n_nodes16 + n_tris16 + n_shade16;
+    lds_free = stage_scene(p, lds_free, sc);
+    __builtin_assume(sc.wide != nullptr);
+  } else {
+    sc.wide = nullptr;
   }
 #ifdef PT_PROFILE
   if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
@@ -812,7 +813,7 @@ void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
-  const size_t scene_bytes = (size_t)p.scene_nodes * 80u + (size_t)p.scene.num_items * (16u * kTriWords) + (size_t)p.scene.num_tris * 96u;
+  const size_t scene_bytes = (size_t)p.scene_nodes * (16u * kWideNodeWords) + (size_t)p.scene.num_items * (16u * kTriWords) + (size_t)p.scene.num_tris * 96u;
   const bool lds_scene = p.scene_in_lds && scene_bytes <= 24u * 1024u;
   size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
   const bool guided = p.guiding || p.train;

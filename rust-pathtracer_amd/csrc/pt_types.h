@@ -216,6 +216,7 @@ struct GuideView {
 
 struct SceneView {
   const BvhNode* nodes;
+  const u4* wide;            // the same nodes unpacked (pt_bvh.h), or null: set by kernels that stage the scene in LDS
   // 4 x q4 per leaf item (a triangle, or two forming a parallelogram) in BVH leaf order (see the record
   // layout in pt_bvh.h): v0 and the rows that map (p - v0) to the barycentrics of v1, v2 and to the distance
   // from the plane

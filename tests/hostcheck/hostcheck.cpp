@@ -53,6 +53,7 @@ void finish_scene() {
     r.home_node = g_bvh.home_node[(size_t)i]; r.home_mask = g_bvh.home_mask[(size_t)i];
   }
   g_sv.nodes = g_bvh.nodes.data();
+  g_sv.wide = nullptr;
   g_sv.tris = g_bvh.tris.data();
   g_sv.shade = g_recs.data();
   g_sv.num_tris = (uint32_t)nt;
@@ -100,6 +101,16 @@ void hc_scene_get(float* v, uint32_t* idx, float* nrm, float* m11) {
   if (m11) memcpy(m11, g_hs.materials.data(), g_hs.materials.size() * sizeof(Material));
 }
 void hc_set_origin_skip(int on) { g_origin_skip = on; }
+// traverse the unpacked form of the nodes (what the fused kernels keep in LDS) instead of the packed one
+std::vector<u4> g_wide;
+void hc_set_wide_nodes(int on) {
+  ensure();
+  g_wide.assign(on ? g_bvh.nodes.size() * kWideNodeWords : 0, u4{0u, 0u, 0u, 0u});
+  if (on)
+    for (size_t k = 0; k < g_bvh.nodes.size() * 8; ++k)
+      unpack_node_slot(g_bvh.nodes[k >> 3], (int)(k & 7), reinterpret_cast<uint32_t*>(g_wide.data() + kWideNodeWords * (k >> 3)));
+  g_sv.wide = on ? g_wide.data() : nullptr;
+}
 // rebuilds the current scene's tree with or without parallelogram items
 void hc_set_pairing(int on) { bvh_set_pairing(on); ensure(); finish_scene(); }
 int hc_num_items() { ensure(); return g_bvh.num_items; }

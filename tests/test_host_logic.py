@@ -202,6 +202,41 @@ def test_parallelogram_items_give_the_triangles_answers(hostcheck):
     assert hostcheck.hc_num_items() == 12  # the built-in scene is twelve quads
 
 
+def test_unpacked_nodes_traverse_like_packed_ones(hostcheck):
+    """The fused kernels keep small scenes' nodes unpacked in LDS (bounds as floats, traversal bits per
+    slot precomputed).  Same arithmetic, so the same hits bit for bit: built-in scene, a deeper tree and the
+    quad scene, closest-hit and any-hit."""
+    import geom_cases
+    rng = np.random.default_rng(5)
+
+    def both(o, d):
+        out = []
+        tmax = rng.uniform(0.2, 4.0, len(o)).astype(np.float32)
+        for wide in (0, 1):
+            hostcheck.hc_set_wide_nodes(wide)
+            out.append(_hc_trace(hostcheck, o, d) + (_hc_trace(hostcheck, o, d, tmax, any_hit=1)[0],))
+        hostcheck.hc_set_wide_nodes(0)
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+        assert (out[0][0] >= 0).mean() > 0.3
+
+    try:
+        hostcheck.hc_scene_cornell()
+        both(*_random_rays(20000, 5))
+        hostcheck.hc_scene_synthetic(7, 64, 2)  # several levels: internal children, every octant order
+        o = rng.uniform(-0.9, 0.9, (20000, 3)).astype(np.float32)
+        o[:, 2] += 1.0
+        d = rng.normal(size=(20000, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        both(o, d)
+        V, I, centre, qrng, n_quads = geom_cases.quad_scene()
+        hostcheck.hc_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
+        both(*geom_cases.quad_rays(V, I, qrng))
+    finally:
+        hostcheck.hc_set_wide_nodes(0)
+        hostcheck.hc_scene_cornell()
+
+
 def test_watertight_no_leak_through_shared_edges(hostcheck):
     """Rays aimed exactly at quad diagonals, edges and corners of the closed part of the box
     must hit something (the two triangles of a quad share their diagonal)."""
