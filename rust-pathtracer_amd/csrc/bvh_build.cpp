@@ -42,7 +42,9 @@ struct Node2 {
 };
 
 constexpr int kBins = 16;
-constexpr int kMaxLeaf = 3;
+// Items per leaf of the binary tree.  One: every item gets its own box in an 8-wide node, which culls better
+// than it costs (measured against 2 and 3 on the built-in scene, +2 %, and on 12.8 M triangles, +5 %).
+constexpr int kMaxLeaf = 1;
 constexpr uint32_t kNoPartner = 0xffffffffu;
 
 // What a leaf slot holds: one triangle, or two triangles that together form a parallelogram (a quad split
