@@ -2,7 +2,7 @@
 // (src/main.rs:437-564): same default parameters, same call sequence against the same C
 // ABI, same output files (pt.exr, pt_bayer.exr) and the same progress lines on stdout.
 // The Rust toolchain is not available to this build; a Rust host binds the identical
-// symbols.
+// symbols through the extern "C" block it already has (src/main.rs:9-32).
 //
 // Differences from main.rs: the render parameters, which main.rs hard-codes
 // (src/main.rs:478-484), can be overridden on the command line; the demosaic runs on the

@@ -50,7 +50,7 @@ def test_product_has_no_oracle_or_cpu_fallback(pt):
 
 
 def test_struct_layouts_match_reference_sizes(pt):
-    # SURVEY of the reference: pgl_region 32 B, pgl_lobe 32 B, TrainSample 40 B (src/guiding.rs:5-28)
+    # sizes in the reference: pgl_region 32 B, pgl_lobe 32 B, TrainSample 40 B (src/guiding.rs:5-28)
     assert C.sizeof(pt.PglRegion) == 32 and C.sizeof(pt.PglLobe) == 32 and C.sizeof(pt.TrainSample) == 40
 
 
