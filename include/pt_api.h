@@ -228,6 +228,21 @@ PT_EXPORT void pt_scene_cornell(void);
 PT_EXPORT void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv);
 PT_EXPORT void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                                   const float* materials11);
+/* Scene input beyond the built-in box (the reference has none: its quads are hard-coded,
+ * optix_wrapper.cpp:379-489).  pt_scene_load_obj reads a Wavefront OBJ file and the material library it names:
+ * v, f (polygons are fanned; v, v/vt, v//vn, v/vt/vn; negative indices), usemtl; Kd = base colour, Ke =
+ * emission, Ni = index of refraction, Pr = roughness (else from Ns), d / Tr = opacity (d < 1: dielectric with
+ * transmission 1 - d).  Returns the number of triangles, or -1 with the reason on stderr (the current scene is
+ * then kept).  pt_scene_save_obj writes the current scene as OBJ + MTL (same path, extension .mtl) with
+ * enough digits to read back the same bits; 0 or -1.  Next-event estimation samples one rectangle light in a
+ * plane of constant z, as in the reference (optix_wrapper.cpp:842-845, optix_device.cu:495-548):
+ * pt_scene_set_light replaces its centre, emission, normal and half extents along x and y (NULL keeps a
+ * field); scene setters reset it to the reference's. */
+PT_EXPORT int  pt_scene_load_obj(const char* path);
+/* Sizes of the current scene on the host (the arrays pt_scene_get fills); needs no GPU. */
+PT_EXPORT void pt_scene_counts(int* n_vertices, int* n_triangles);
+PT_EXPORT int  pt_scene_save_obj(const char* path);
+PT_EXPORT void pt_scene_set_light(const float pos[3], const float emit[3], const float normal[3], const float half[2]);
 /* Leaf items of the BVH: 1 (default) lets two consecutive triangles that form a parallelogram -- a quad
  * split along a diagonal -- share one traversal record and one plane intersection, 0 keeps every triangle
  * on its own, < 0 returns to the default (environment PT_BVH_PAIRS).  Results are the same primitives and

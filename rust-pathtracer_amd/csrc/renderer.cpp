@@ -918,6 +918,41 @@ void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* i
   g_scene_init = true;
   g_scene_version++;
 }
+void pt_scene_counts(int* n_vertices, int* n_triangles) {
+  HostScene& hs = scene();
+  if (n_vertices) *n_vertices = (int)(hs.vertices.size() / 3);
+  if (n_triangles) *n_triangles = hs.num_tris();
+}
+int pt_scene_load_obj(const char* path) {
+  HostScene loaded;
+  std::string err;
+  if (!path || !load_obj(path, loaded, err)) {
+    fprintf(stderr, "[pt_hip] pt_scene_load_obj: %s\n", path ? err.c_str() : "null path");
+    return -1;
+  }
+  g_scene = std::move(loaded);
+  g_scene_init = true;
+  g_scene_version++;
+  return g_scene.num_tris();
+}
+int pt_scene_save_obj(const char* path) {
+  std::string err;
+  if (!path || !save_obj(path, scene(), err)) {
+    fprintf(stderr, "[pt_hip] pt_scene_save_obj: %s\n", path ? err.c_str() : "null path");
+    return -1;
+  }
+  return 0;
+}
+void pt_scene_set_light(const float pos[3], const float emit[3], const float normal[3], const float half[2]) {
+  HostScene& hs = scene();
+  for (int k = 0; k < 3; ++k) {
+    if (pos) hs.light_pos[k] = pos[k];
+    if (emit) hs.light_emit[k] = emit[k];
+    if (normal) hs.light_normal[k] = normal[k];
+  }
+  if (half) { hs.light_half[0] = half[0]; hs.light_half[1] = half[1]; }
+  g_scene_version++;
+}
 void pt_set_bvh_pairing(int on) {
   bvh_set_pairing(on);
   g_scene_version++;  // the next render rebuilds the tree

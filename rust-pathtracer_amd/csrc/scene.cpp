@@ -68,6 +68,8 @@ void add_room(HostScene& s) {
 
 }  // namespace
 
+void set_default_light(HostScene& s) { set_light(s); }
+
 void HostScene::compute_normals() {
   // optix_wrapper.cpp:466-476
   const size_t nt = indices.size() / 3;

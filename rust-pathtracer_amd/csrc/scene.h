@@ -1,6 +1,7 @@
 // scene.h -- host-side scene description: triangle soup + per-triangle materials.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 namespace pt {
@@ -36,5 +37,10 @@ HostScene make_synthetic(uint32_t seed, int n_objects, int subdiv);
 // Caller geometry inside the reference's light set-up; materials11 may be null (white diffuse).
 HostScene make_from_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                               const float* materials11);
+
+// Wavefront OBJ (+ MTL) in and out (scene_obj.cpp).  A loaded scene keeps the reference's rectangle light
+// for next-event estimation until the caller sets another one.  On failure `err` says why.
+bool load_obj(const char* path, HostScene& out, std::string& err);
+bool save_obj(const char* path, const HostScene& scene, std::string& err);
 
 }  // namespace pt

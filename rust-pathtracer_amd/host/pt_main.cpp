@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
       int n = 0, sub = 3;
       if (v == "cornell") pt_scene_cornell();
       else if (sscanf(v.c_str(), "synthetic:%d:%d", &n, &sub) >= 1) pt_scene_synthetic(42u, n, sub);
+      else if (pt_scene_load_obj(v.c_str()) < 0) return 2;  // anything else is the path of an OBJ file
     }
     else if (arg_value(a, "--out", v)) out_rgb = v;
     else if (arg_value(a, "--out-bayer", v)) out_bayer = v;

@@ -105,6 +105,10 @@ SIGNATURES = {
     "pt_scene_synthetic": (None, [C.c_uint32, C.c_int, C.c_int]),
     "pt_scene_triangles": (None, [_fp, C.c_int, _u32p, C.c_int, _fp]),
     "pt_set_bvh_pairing": (None, [C.c_int]),
+    "pt_scene_load_obj": (C.c_int, [C.c_char_p]),
+    "pt_scene_counts": (None, [_ip, _ip]),
+    "pt_scene_save_obj": (C.c_int, [C.c_char_p]),
+    "pt_scene_set_light": (None, [_fp, _fp, _fp, _fp]),
     "pt_scene_info": (None, [_ip, _ip, _ip, C.POINTER(C.c_size_t)]),
     "pt_scene_get": (None, [_fp, _u32p, _fp, _fp]),
     "pt_dbg_pcg": (C.c_int, [C.c_uint64, C.c_int, _u32p, _fp]),
@@ -259,6 +263,18 @@ def kernel_stats(kernel):
     ms, timed, launches, work = C.c_double(), C.c_uint64(), C.c_uint64(), C.c_uint64()
     lib().pt_get_kernel_stats(kernel, C.byref(ms), C.byref(timed), C.byref(launches), C.byref(work))
     return {"total_ms": ms.value, "timed": timed.value, "launches": launches.value, "work": work.value}
+
+
+def scene_arrays():
+    """(vertices [nv,3], indices [nt,3], normals [nt,3], materials [nt,11]) of the current scene; needs no GPU."""
+    nv, nt = C.c_int(), C.c_int()
+    lib().pt_scene_counts(C.byref(nv), C.byref(nt))
+    V = np.zeros((nv.value, 3), np.float32)
+    I = np.zeros((nt.value, 3), np.uint32)
+    N = np.zeros((nt.value, 3), np.float32)
+    M = np.zeros((nt.value, 11), np.float32)
+    lib().pt_scene_get(_f(V), I.ctypes.data_as(_u32p), _f(N), _f(M))
+    return V, I, N, M
 
 
 def scene_info():

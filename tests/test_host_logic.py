@@ -564,3 +564,85 @@ def test_shared_adaptive_reduce_two_ranks(tmp_path):
     assert (first[:, 0] == 3).all() and (first[:, 3] == 4).all() and (first[:, 4] == 5).all()
     # after three rounds: sums (1+2)*(1+2+3) = 18 over 2 * 3 * 2 = 12 samples
     assert (a["cnt"] == 12).all() and np.allclose(a["mean"], 1.5)
+
+
+# ------------------------------------------------------------------ scene input (OBJ / MTL)
+_OBJ = """# a quad with texture/normal references, a pentagon with negative indices, a glass triangle
+mtllib things.mtl
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vt 0 0
+vn 0 0 1
+usemtl red
+f 1/1/1 2/1/1 3/1/1 4/1/1
+v 2 0 1
+v 3 0 1
+v 3.5 1 1
+v 2.5 2 1
+v 1.5 1 1
+usemtl lamp
+f -5 -4 -3 -2 -1
+usemtl glass
+f 1//1 5//1 9//1
+usemtl missing
+f 1 2 5
+"""
+_MTL = """newmtl red
+Kd 0.5 0.1 0.05
+Ns 98
+newmtl lamp
+Kd 0 0 0
+Ke 7 8 9
+Pr 0.6
+Ns 10
+newmtl glass
+Kd 1 1 1
+Ni 1.33
+d 0.25
+Pr 0
+"""
+
+
+def test_obj_scene_input(pt, tmp_path):
+    """Wavefront OBJ in: polygons are fanned from their first corner into consecutive triangles, index forms
+    and negative indices resolve, materials come from the library (missing ones fall back to the default)."""
+    (tmp_path / "things.obj").write_text(_OBJ)
+    (tmp_path / "things.mtl").write_text(_MTL)
+    L = pt.lib()
+    try:
+        assert L.pt_scene_load_obj(str(tmp_path / "things.obj").encode()) == 2 + 3 + 1 + 1
+        V, I, N, M = pt.scene_arrays()
+        assert V.shape == (9, 3) and I.tolist() == [[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [4, 7, 8], [0, 4, 8], [0, 1, 4]]
+        assert np.allclose(N[0], [0, 0, 1]) and np.allclose(N[1], [0, 0, 1])
+        red, lamp, glass, default = M[0], M[2], M[5], M[6]
+        assert np.array_equal(M[0], M[1]) and np.array_equal(M[2], M[4])
+        assert np.allclose(red[0:3], [0.5, 0.1, 0.05]) and red[4] == pytest.approx(np.sqrt(2 / 100.0)) and red[7] == 0
+        assert np.allclose(lamp[8:11], [7, 8, 9]) and lamp[4] == pytest.approx(0.6)  # Pr wins over Ns
+        assert glass[5] == pytest.approx(1.33) and glass[7] == pytest.approx(0.75) and glass[4] == 0
+        assert np.allclose(default[0:3], [0.789, 0.801, 0.8]) and default[4] == pytest.approx(0.25) and default[5] == pytest.approx(1.5)
+        # errors leave the scene as it was
+        assert L.pt_scene_load_obj(str(tmp_path / "nothing.obj").encode()) == -1
+        (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2 7\n")
+        assert L.pt_scene_load_obj(str(tmp_path / "bad.obj").encode()) == -1
+        assert pt.scene_arrays()[1].shape == (7, 3)
+    finally:
+        L.pt_scene_cornell()
+
+
+def test_obj_round_trip_is_exact(pt, tmp_path):
+    """The built-in scene written as OBJ + MTL and read back is the same scene, bit for bit."""
+    L = pt.lib()
+    L.pt_scene_cornell()
+    want = pt.scene_arrays()
+    path = str(tmp_path / "cornell.obj").encode()
+    assert L.pt_scene_save_obj(path) == 0
+    try:
+        assert L.pt_scene_load_obj(path) == 24
+        got = pt.scene_arrays()
+        # the file holds only the vertices, so duplicates stay duplicates and the order is kept
+        for a, b in zip(want, got):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    finally:
+        L.pt_scene_cornell()
