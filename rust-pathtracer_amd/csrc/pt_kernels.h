@@ -19,6 +19,7 @@ struct RenderParams {
   int sample_begin, sample_count;  // this call renders global samples [begin, begin+count) per pixel
   uint32_t npx;                    // width * height
   int chunks, chunk_spp;           // the range is split into `chunks` slots per pixel of chunk_spp samples
+  int round_limit;                 // > 0: no slot goes beyond this many samples yet (adaptive rounds)
   int strict;                      // 1: replay the reference's 4-sample launches literally
   int guiding;
   int stack_depth;                 // traversal stack entries per lane
@@ -72,15 +73,19 @@ struct AdaptiveBuffers {
   uint32_t* count;      // one word: length of the list k_noise_select writes (cleared by the caller)
   uint32_t* noise_map;  // float bits, compared as unsigned (values are >= 0)
   float* own_noise;
+  int* total;           // samples of the pixel over all its slots, as of the last test
 };
 // One evaluation at a round boundary: reads active[which] (n_active pixels), writes the pixels that stay
 // active to active[which ^ 1] and their number to *count.
+// acc / acc2 / started hold `chunks` slots per pixel (slot = chunk * w*h + pixel), added up in chunk order.
 void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, const q4* acc, const q4* acc2,
-                        const int* started, int w, int h, int pattern, int min_samples, int spp, float threshold,
-                        hipStream_t s);
+                        const int* started, int chunks, int w, int h, int pattern, int min_samples, int spp,
+                        float threshold, hipStream_t s);
+// queue[i * chunks + c] = active[i] + c * npx: the slots of the active pixels
+void launch_expand_active(const uint32_t* active, uint32_t n_active, int chunks, uint32_t npx, uint32_t* queue, hipStream_t s);
 
 // per-pixel statistics as 8 floats (sum rgb, samples, sum of squares rgb, 0) and back; count = round(samples)
-void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, float* stats, uint32_t npx, hipStream_t s);
+void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, int chunks, float* stats, uint32_t npx, hipStream_t s);
 void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx, hipStream_t s);
 
 // profiling build (-DPT_PROFILE) only: section counters, (waves, lanes) pairs; returns the number of sections

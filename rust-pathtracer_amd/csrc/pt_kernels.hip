@@ -87,6 +87,7 @@ __device__ __forceinline__ Slot decode_slot(const RenderParams& p, uint32_t slot
   s.begin = p.sample_begin + (int)chunk * p.chunk_spp;
   const int rem = p.sample_count - (int)chunk * p.chunk_spp;
   s.count = rem < p.chunk_spp ? (rem > 0 ? rem : 0) : p.chunk_spp;
+  if (p.round_limit > 0 && s.count > p.round_limit) s.count = p.round_limit;
   return s;
 }
 // Sample index fed to the jitter hash, and the PCG state the sample starts from.
@@ -683,15 +684,35 @@ __device__ __forceinline__ float pixel_noise(q4 s1, q4 s2, int n, int ch) {
 __global__ void k_noise_clear(const uint32_t* active, uint32_t n, uint32_t* noise_map) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) noise_map[active[i]] = 0u;
 }
+// statistics of a pixel: its slots added up in chunk order
+struct PixelStats {
+  q4 s1, s2;
+  int n;
+};
+__device__ __forceinline__ PixelStats pixel_stats(const q4* acc, const q4* acc2, const int* started, uint32_t px,
+                                                  uint32_t npx, int chunks) {
+  PixelStats r{acc[px], acc2[px], started[px]};
+  for (int k = 1; k < chunks; ++k) {
+    const size_t i = (size_t)k * npx + px;
+    const q4 a = acc[i], b = acc2[i];
+    r.s1.x += a.x; r.s1.y += a.y; r.s1.z += a.z;
+    r.s2.x += b.x; r.s2.y += b.y; r.s2.z += b.z;
+    r.n += started[i];
+  }
+  return r;
+}
 __global__ void k_noise_raise(const uint32_t* active, uint32_t n, const q4* acc, const q4* acc2, const int* started,
-                              uint32_t* noise_map, float* own_noise, int w, int h, int pattern, int min_samples) {
+                              int chunks, uint32_t* noise_map, float* own_noise, int* total, int w, int h, int pattern,
+                              int min_samples) {
+  const uint32_t npx = (uint32_t)w * (uint32_t)h;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const uint32_t px = active[i];
-    const int cnt = started[px];
+    const PixelStats st = pixel_stats(acc, acc2, started, px, npx, chunks);
+    const int cnt = st.n;
     float noise = -1.0f;
     if (cnt >= min_samples && cnt > 1) {
       const int y = (int)(px / (uint32_t)w), x = (int)(px - (uint32_t)y * (uint32_t)w);
-      noise = pixel_noise(acc[px], acc2[px], cnt, bayer_channel_for(x, y, pattern));
+      noise = pixel_noise(st.s1, st.s2, cnt, bayer_channel_for(x, y, pattern));
       const uint32_t bits = f2u(noise);  // noise >= 0: float order == unsigned order of the bits
       for (int dy = -1; dy <= 1; ++dy)
         for (int dx = -1; dx <= 1; ++dx) {
@@ -701,10 +722,11 @@ __global__ void k_noise_raise(const uint32_t* active, uint32_t n, const q4* acc,
         }
     }
     own_noise[px] = noise;
+    total[px] = cnt;
   }
 }
 __global__ void __launch_bounds__(256) k_noise_select(const uint32_t* active, uint32_t n, const uint32_t* noise_map,
-                                                      const float* own_noise, const int* started, int w, int h, int spp,
+                                                      const float* own_noise, const int* total, int w, int h, int spp,
                                                       float threshold, uint32_t* out, uint32_t* out_count) {
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
@@ -713,7 +735,7 @@ __global__ void __launch_bounds__(256) k_noise_select(const uint32_t* active, ui
     if (i < n) {
       px = active[i];
       const float own = own_noise[px];
-      keep = started[px] < spp;
+      keep = total[px] < spp;
       if (own >= 0.f) {
         const int y = (int)(px / (uint32_t)w), x = (int)(px - (uint32_t)y * (uint32_t)w);
         float mx = own;
@@ -730,15 +752,22 @@ __global__ void __launch_bounds__(256) k_noise_select(const uint32_t* active, ui
     if (keep) out[slot] = px;
   }
 }
+__global__ void k_expand_active(const uint32_t* active, uint32_t n, int chunks, uint32_t npx, uint32_t* queue) {
+  const uint32_t total = n * (uint32_t)chunks;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t a = i / (uint32_t)chunks, c = i - a * (uint32_t)chunks;
+    queue[i] = active[a] + c * npx;
+  }
+}
 
 // Statistics of every pixel as eight floats (sum r g b, samples taken, sum of squares r g b, 0): the form in
 // which ranks of a sample-sharded adaptive render add their shares together, and its inverse.
-__global__ void k_pack_stats(const q4* acc, const q4* acc2, const int* started, float* stats, uint32_t npx) {
+__global__ void k_pack_stats(const q4* acc, const q4* acc2, const int* started, int chunks, float* stats, uint32_t npx) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
-    const q4 a = acc[i], b = acc2[i];
+    const PixelStats st = pixel_stats(acc, acc2, started, i, npx, chunks);
     q4* out = reinterpret_cast<q4*>(stats) + 2 * (size_t)i;
-    out[0] = q4{a.x, a.y, a.z, (float)started[i]};
-    out[1] = q4{b.x, b.y, b.z, 0.f};
+    out[0] = q4{st.s1.x, st.s1.y, st.s1.z, (float)st.n};
+    out[1] = q4{st.s2.x, st.s2.y, st.s2.z, 0.f};
   }
 }
 __global__ void k_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx) {
@@ -851,8 +880,8 @@ void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s) {
   k_iota<<<1024, 256, 0, s>>>(dst, n);
   PT_KCHECK();
 }
-void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, float* stats, uint32_t npx, hipStream_t s) {
-  k_pack_stats<<<1024, 256, 0, s>>>(acc, acc2, started, stats, npx);
+void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, int chunks, float* stats, uint32_t npx, hipStream_t s) {
+  k_pack_stats<<<1024, 256, 0, s>>>(acc, acc2, started, chunks, stats, npx);
   PT_KCHECK();
 }
 void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx, hipStream_t s) {
@@ -860,17 +889,22 @@ void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint
   PT_KCHECK();
 }
 void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, const q4* acc, const q4* acc2,
-                        const int* started, int w, int h, int pattern, int min_samples, int spp, float threshold,
-                        hipStream_t s) {
+                        const int* started, int chunks, int w, int h, int pattern, int min_samples, int spp,
+                        float threshold, hipStream_t s) {
   const int blocks = (int)((n_active + 255u) / 256u < 2048u ? (n_active + 255u) / 256u : 2048u);
   if (blocks <= 0) return;
   k_noise_clear<<<blocks, 256, 0, s>>>(a.active[which], n_active, a.noise_map);
   PT_KCHECK();
-  k_noise_raise<<<blocks, 256, 0, s>>>(a.active[which], n_active, acc, acc2, started, a.noise_map, a.own_noise, w, h,
-                                       pattern, min_samples);
+  k_noise_raise<<<blocks, 256, 0, s>>>(a.active[which], n_active, acc, acc2, started, chunks, a.noise_map, a.own_noise,
+                                       a.total, w, h, pattern, min_samples);
   PT_KCHECK();
-  k_noise_select<<<blocks, 256, 0, s>>>(a.active[which], n_active, a.noise_map, a.own_noise, started, w, h, spp, threshold,
+  k_noise_select<<<blocks, 256, 0, s>>>(a.active[which], n_active, a.noise_map, a.own_noise, a.total, w, h, spp, threshold,
                                         a.active[which ^ 1], a.count);
+  PT_KCHECK();
+}
+void launch_expand_active(const uint32_t* active, uint32_t n_active, int chunks, uint32_t npx, uint32_t* queue, hipStream_t s) {
+  if (n_active == 0) return;
+  k_expand_active<<<1024, 256, 0, s>>>(active, n_active, chunks, npx, queue);
   PT_KCHECK();
 }
 void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s) {

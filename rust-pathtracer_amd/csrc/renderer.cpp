@@ -39,6 +39,7 @@ uint64_t g_rays_total[2] = {0, 0};
 int g_fused_bounces = 16;
 int g_defer_shadow = getenv("PT_DEFER_SHADOW") ? atoi(getenv("PT_DEFER_SHADOW")) : 1;
 int g_adaptive_round = getenv("PT_ADAPTIVE_ROUND") ? atoi(getenv("PT_ADAPTIVE_ROUND")) : -32;
+int g_adaptive_chunks = getenv("PT_ADAPTIVE_CHUNKS") ? atoi(getenv("PT_ADAPTIVE_CHUNKS")) : 0;  // 0: as many as fit
 constexpr size_t kTargetSlots = 8u << 20;  // path slots worth keeping in flight (pixels x chunks)
 
 int env_choice(const char* name, const char* a, const char* b, int dflt) {
@@ -500,12 +501,13 @@ void render_core(State& s, int sample_begin, int sample_count, int max_depth, in
 void ensure_adaptive(State& s) {
   if (s.acc2) return;
   const size_t px = (size_t)s.width * (size_t)s.height;
-  s.acc2 = dev_alloc<q4>(px);
+  s.acc2 = dev_alloc<q4>(px * (size_t)s.max_chunks);
   s.adaptive.active[0] = dev_alloc<uint32_t>(px);
   s.adaptive.active[1] = dev_alloc<uint32_t>(px);
   s.adaptive.count = dev_alloc<uint32_t>(1);
   s.adaptive.noise_map = dev_alloc<uint32_t>(px);
   s.adaptive.own_noise = dev_alloc<float>(px);
+  s.adaptive.total = dev_alloc<int>(px);
 }
 
 // Statistics shared between the ranks of a sample-sharded adaptive render: at every round boundary each
@@ -524,11 +526,6 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
                     int min_samples, const SharedStats* shared = nullptr) {
   ensure_adaptive(s);
   RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict);
-  p.chunks = 1;
-  p.chunk_spp = spp;
-  p.acc2 = s.acc2;
-  RenderLoop loop(s, p);
-  s.last_chunks = 1;
   const uint32_t npx = p.npx;
   if (shared && !s.shared_acc) {
     s.shared_acc = dev_alloc<q4>(npx);
@@ -540,17 +537,33 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
   auto local_target = [&](int t) {
     return shared ? (int)std::min<long long>(spp, ((long long)t * spp + total - 1) / total) : t;
   };
+  // strict mode replays the reference's 4-sample launches, so it is tested at that cadence
+  const bool doubling = !strict && g_adaptive_round < 0;
+  const int round = strict ? 4 : std::max(std::abs(g_adaptive_round), 1);
+  auto next_target = [&](int d) { return doubling ? (d == 0 ? round : 2 * d) : d + round; };
+  // A pixel's samples are rendered as several chunks side by side (one slot each) where that keeps enough
+  // paths in flight; every chunk takes the same number of samples per round, so the chunk count has to
+  // divide this rank's share of a round (and of the first target, which may be several rounds away).
+  int first = next_target(0);
+  while (first < min_samples && first < total) first = next_target(first);
+  int chunks = 1;
+  if (!strict) {
+    const int cap = g_adaptive_chunks > 0 ? std::min(g_adaptive_chunks, s.max_chunks) : s.max_chunks;
+    const int step = local_target(std::min(round, total)), start = local_target(std::min(first, total));
+    while (2 * chunks <= cap && step % (2 * chunks) == 0 && start % (2 * chunks) == 0 && step / (2 * chunks) >= 4) chunks *= 2;
+  }
+  p.chunks = chunks;
+  p.chunk_spp = (spp + chunks - 1) / chunks;
+  p.acc2 = s.acc2;
+  RenderLoop loop(s, p);
+  s.last_chunks = chunks;
   auto exchange = [&]() -> int {
-    launch_pack_stats(s.acc, s.acc2, s.started, shared->stats, npx, s.stream);
+    launch_pack_stats(s.acc, s.acc2, s.started, chunks, shared->stats, npx, s.stream);
     HIP_CHECK(hipStreamSynchronize(s.stream));
     const int rc = shared->reduce ? shared->reduce(shared->user) : 0;
     HIP_CHECK(hipSetDevice(s.device));
     return rc;
   };
-  // strict mode replays the reference's 4-sample launches, so it is tested at that cadence
-  const bool doubling = !strict && g_adaptive_round < 0;
-  const int round = strict ? 4 : std::max(std::abs(g_adaptive_round), 1);
-  auto next_target = [&](int d) { return doubling ? (d == 0 ? round : 2 * d) : d + round; };
   loop.begin();
   loop.reset_slots();
   HIP_CHECK(hipMemsetAsync(s.adaptive.noise_map, 0, (size_t)npx * sizeof(uint32_t), s.stream));
@@ -564,11 +577,9 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
     target = std::min(target, total);
     const int mine = local_target(target);
     if (mine > done_local) {
-      loop.p.sample_count = mine;
-      loop.p.chunk_spp = mine;
-      HIP_CHECK(hipMemcpyAsync(s.queue[0], s.adaptive.active[which], (size_t)n_active * sizeof(uint32_t),
-                               hipMemcpyDeviceToDevice, s.stream));
-      loop.drain(n_active);
+      loop.p.round_limit = (mine + chunks - 1) / chunks;  // per slot; the last chunk of a pixel may hold fewer
+      launch_expand_active(s.adaptive.active[which], n_active, chunks, npx, s.queue[0], s.stream);
+      loop.drain(n_active * (uint32_t)chunks);
       done_local = mine;
     }
     done = target;
@@ -576,13 +587,15 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
     if (done >= total) break;
     const q4 *t_acc = s.acc, *t_acc2 = s.acc2;
     const int* t_n = s.started;
+    int t_chunks = chunks;
     if (shared) {
       if ((rc = exchange()) != 0) break;
       launch_unpack_stats(shared->stats, s.shared_acc, s.shared_acc2, s.shared_n, npx, s.stream);
       t_acc = s.shared_acc; t_acc2 = s.shared_acc2; t_n = s.shared_n;
+      t_chunks = 1;
     }
     HIP_CHECK(hipMemsetAsync(s.adaptive.count, 0, sizeof(uint32_t), s.stream));
-    launch_noise_round(s.adaptive, which, n_active, t_acc, t_acc2, t_n, s.width, s.height, s.bayer_pattern,
+    launch_noise_round(s.adaptive, which, n_active, t_acc, t_acc2, t_n, t_chunks, s.width, s.height, s.bayer_pattern,
                        min_samples, total, threshold, s.stream);
     HIP_CHECK(hipMemcpyAsync(s.h_counters + 2 * CNT_WORDS, s.adaptive.count, sizeof(uint32_t), hipMemcpyDeviceToHost,
                              s.stream));
@@ -633,7 +646,7 @@ State::~State() {
   dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started);
   dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
-  dev_free(adaptive.noise_map); dev_free(adaptive.own_noise);
+  dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);
   dev_free(shared_acc); dev_free(shared_acc2); dev_free(shared_n);
   dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_demosaic_tmp);
   dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid);
@@ -876,6 +889,8 @@ void pt_set_defer_shadow(int on) { g_defer_shadow = on ? 1 : 0; }
 int pt_get_defer_shadow(void) { return g_defer_shadow; }
 void pt_set_adaptive_round(int samples) { g_adaptive_round = samples != 0 ? samples : -32; }
 int pt_get_adaptive_round(void) { return g_adaptive_round; }
+void pt_set_adaptive_chunks(int chunks) { g_adaptive_chunks = chunks > 0 ? chunks : 0; }
+int pt_get_adaptive_chunks(void) { return g_adaptive_chunks; }
 int pt_get_sample_counts(int* out_counts, int* out_rounds) {
   if (!g_handle) return -1;
   State& s = *g_handle;

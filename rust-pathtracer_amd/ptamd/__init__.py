@@ -100,6 +100,8 @@ SIGNATURES = {
     "pt_get_defer_shadow": (C.c_int, []),
     "pt_set_adaptive_round": (None, [C.c_int]),
     "pt_get_adaptive_round": (C.c_int, []),
+    "pt_set_adaptive_chunks": (None, [C.c_int]),
+    "pt_get_adaptive_chunks": (C.c_int, []),
     "pt_get_sample_counts": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pt_scene_cornell": (None, []),
     "pt_scene_synthetic": (None, [C.c_uint32, C.c_int, C.c_int]),

@@ -693,6 +693,7 @@ def test_adaptive_sampling_matches_oracle(gpu, oracle, pipeline):
     L.pt_set_pipeline(pipeline)
     L.pt_set_mode(gpu.MODE_CONVERGE)
     L.pt_set_adaptive_round(rnd)
+    L.pt_set_adaptive_chunks(1)  # one random stream per pixel, as in the oracle
     L.pt_set_frame(0)
     L.pt_reset_ray_counts()
     img = gpu.render_rgb(w, h, spp, noise_threshold=thr, min_adaptive_samples=mn)
@@ -737,6 +738,43 @@ def test_adaptive_sampling_matches_oracle(gpu, oracle, pipeline):
     assert np.allclose(full[lit], plain[lit], rtol=1e-5, atol=1e-6)
     c_plain, r_plain = gpu.sample_counts(w, h)
     assert (c_plain == 48).all() and r_plain == 0
+    L.pt_set_adaptive_chunks(0)
+
+
+def test_adaptive_chunks(gpu):
+    """By default an adaptive render splits a pixel's samples into chunks rendered side by side (more paths
+    in flight, shorter tail per round).  Same rounds, same criterion: counts land on the round boundaries, the
+    count map and the image agree with the one-stream render as two renders with different random numbers
+    do, and the result is reproducible."""
+    L = gpu.lib()
+    w, h, spp, thr, mn = 96, 32, 256, 1.5, 32
+    L.pt_set_mode(gpu.MODE_CONVERGE)
+    L.pt_set_adaptive_round(-32)
+    out = {}
+    for chunks in (1, 0, 0, 4):
+        L.pt_set_adaptive_chunks(chunks)
+        L.pt_set_frame(0)
+        img = gpu.render_rgb(w, h, spp, noise_threshold=thr, min_adaptive_samples=mn)
+        counts, rounds = gpu.sample_counts(w, h)
+        assert set(np.unique(counts)) <= {32, 64, 128, 256} and rounds <= 4
+        assert (counts[:, 0] == mn).all()
+        if chunks == 0 and 0 in out:
+            assert np.array_equal(out[0][0], img) and np.array_equal(out[0][1], counts)
+        out[chunks] = (img, counts)
+    L.pt_set_adaptive_chunks(0)
+    one, auto, four = out[1], out[0], out[4]
+    assert not np.array_equal(one[0], auto[0])  # other random streams
+    for other in (auto, four):
+        assert (other[1] == one[1]).mean() > 0.6
+        assert abs(other[1].mean() - one[1].mean()) / one[1].mean() < 0.06
+        assert abs(other[0].mean() - one[0].mean()) / one[0].mean() < 0.05
+    # fixed rounds of 10 samples: 2 chunks of 5 would leave fewer than 4 per chunk and round -> one chunk... 40: 8 chunks
+    L.pt_set_adaptive_round(40)
+    L.pt_set_frame(0)
+    gpu.render_rgb(w, h, 200, noise_threshold=thr, min_adaptive_samples=mn)
+    c40, _ = gpu.sample_counts(w, h)
+    assert set(np.unique(c40)) <= {40, 80, 120, 160, 200} and (c40[:, 0] == 40).all()
+    L.pt_set_adaptive_round(-32)
 
 
 def test_adaptive_shares_accumulate(gpu):
