@@ -203,7 +203,7 @@ struct NodeWords {
   u4 q[5];
 };
 PT_HD NodeWords load_node(const BvhNode* nodes, uint32_t idx) {
-  const u4* p = reinterpret_cast<const u4*>(nodes) + 5u * idx;
+  const u4* p = reinterpret_cast<const u4*>(nodes) + 8u * idx;
   NodeWords n;
   n.q[0] = p[0]; n.q[1] = p[1]; n.q[2] = p[2]; n.q[3] = p[3]; n.q[4] = p[4];
   return n;

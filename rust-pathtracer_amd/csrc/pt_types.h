@@ -158,9 +158,10 @@ struct alignas(16) u4 {
   uint32_t x, y, z, w;
 };
 
-// Compressed 8-wide BVH node, 80 bytes (layout after Ylitie, Karras, Laine 2017):
+// Compressed 8-wide BVH node, 80 bytes padded to a 128-byte cache line so that a visit touches one line
+// (layout after Ylitie, Karras, Laine 2017):
 // child boxes are 8-bit offsets on a per-node grid p + q * 2^e.
-struct alignas(16) BvhNode {
+struct alignas(128) BvhNode {
   float px, py, pz;        // grid origin = node box minimum
   uint8_t ex, ey, ez;      // biased float exponents of the grid step per axis
   uint8_t imask;           // bit s set: slot s holds an internal child
@@ -169,8 +170,9 @@ struct alignas(16) BvhNode {
   uint8_t meta[8];         // per slot: 0 empty; internal (1<<5)|(24+slot); leaf (unary count<<5)|first triangle offset
   uint8_t qlox[8], qloy[8], qloz[8];
   uint8_t qhix[8], qhiy[8], qhiz[8];
+  uint8_t pad_[48];
 };
-static_assert(sizeof(BvhNode) == 80, "BvhNode must be 80 bytes");
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 
 // Per-triangle shading record, indexed by the scene's primitive index (96 bytes).
 struct alignas(16) ShadeRec {

@@ -231,12 +231,12 @@ def test_parallelogram_items(gpu):
         o, d = geom_cases.quad_rays(V, I, rng, 20000)
         prim, t, b1, b2 = gpu.trace_rays(o, d)
         info = gpu.scene_info()
-        assert (info["bvh_bytes"] - 80 * info["nodes"]) // 64 == len(I) - n_quads
+        assert (info["bvh_bytes"] - 128 * info["nodes"]) // 64 == len(I) - n_quads
         geom_cases.check_against_float64(V, I, o, d, prim, t, b1, b2)
         L.pt_set_bvh_pairing(0)
         prim0, t0, b10, b20 = gpu.trace_rays(o, d)
         info = gpu.scene_info()
-        assert (info["bvh_bytes"] - 80 * info["nodes"]) // 64 == len(I)
+        assert (info["bvh_bytes"] - 128 * info["nodes"]) // 64 == len(I)
         same = prim == prim0
         assert same.mean() > 0.98
         hit = same & (prim >= 0)
