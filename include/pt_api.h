@@ -235,6 +235,10 @@ PT_EXPORT void pt_scene_cornell(void);
 PT_EXPORT void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv);
 PT_EXPORT void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                                   const float* materials11);
+/* pgl_samples_add_surface for `count` records in the layout guiding_map_train_samples returns (the host loop
+ * of src/guiding.rs:196-219 in one call); used by multi-GPU hosts that gather every rank's ring on one rank. */
+PT_EXPORT void pt_pgl_samples_add_batch(pgl_samples_t samples, const TrainSample* records, uint32_t count);
+
 /* Scene input beyond the built-in box (the reference has none: its quads are hard-coded,
  * optix_wrapper.cpp:379-489).  pt_scene_load_obj reads a Wavefront OBJ file and the material library it names:
  * v, f (polygons are fanned; v, v/vt, v//vn, v/vt/vn; negative indices), usemtl; Kd = base colour, Ke =

@@ -7,9 +7,13 @@
 // simpler field on the host: a fixed grid of regions over the scene bounds, each holding up
 // to six von Mises-Fisher lobes fitted by weighted moments.  What it shares with the bridge:
 //   * sample weight = mean of the RGB weight, pdf 1, distance 0 (openpgl_bridge.cpp:47-58)
-//   * per-lobe RGB = sum of the sample colours assigned to the lobe with the largest
-//     dot(direction, mu) in the sample's region (openpgl_bridge.cpp:95-119)
+//   * per-lobe RGB from the sample colours assigned to the lobe with the largest
+//     dot(direction, mu) in the sample's region (openpgl_bridge.cpp:95-119).  The bridge stores
+//     their SUM, and the integrator multiplies the path throughput by it (optix_device.cu:629, 653-654):
+//     with real training data that multiplies radiance by the number of samples per lobe.  (It never
+//     shows in the reference because its training ring stays empty.)  Here the MEAN colour is stored.
 //   * snapshot layout pgl_region / pgl_lobe with lobe_ofs / lobe_num (126-193)
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +39,7 @@ struct StubLobe {
   double r[3] = {0, 0, 0};  // weighted sum of directions
   double w = 0;             // sum of weights
   double rgb[3] = {0, 0, 0};
+  double count = 0;         // samples assigned
   float mu[3] = {0, 0, 1};  // current mean direction used for assignment
 };
 struct StubRegion {
@@ -94,6 +99,14 @@ void pgl_samples_add_surface(pgl_samples_t handle, const float pos[3], const flo
   s->items.push_back(it);
 }
 
+// Many records at once, in the layout guiding_map_train_samples returns (src/guiding.rs:196-219 adds them one
+// by one): what a host uses that has gathered the rings of several GPUs.
+void pt_pgl_samples_add_batch(pgl_samples_t handle, const TrainSample* records, uint32_t count) {
+  if (!handle || !records) return;
+  for (uint32_t i = 0; i < count; ++i)
+    pgl_samples_add_surface(handle, records[i].position, records[i].dir_in, records[i].contrib, (int)records[i].is_delta);
+}
+
 void pgl_field_update(pgl_field_t field_handle, pgl_samples_t samples_handle) {
   StubField* f = static_cast<StubField*>(field_handle);
   StubSamples* s = static_cast<StubSamples*>(samples_handle);
@@ -122,6 +135,7 @@ void pgl_field_update(pgl_field_t field_handle, pgl_samples_t samples_handle) {
       lb.rgb[k] += it.rgb[k];
     }
     lb.w += it.weight;
+    lb.count += 1.0;
   }
   // refresh the assignment directions from the accumulated moments
   for (StubRegion& reg : f->regions)
@@ -166,7 +180,7 @@ void pgl_field_snapshot(pgl_field_t field_handle, const struct pgl_region** regi
             pgl_lobe l;
             for (int k = 0; k < 3; ++k) {
               l.mu[k] = lb.mu[k];
-              l.rgb[k] = (float)lb.rgb[k];
+              l.rgb[k] = (float)(lb.rgb[k] / std::max(lb.count, 1.0));
             }
             l.kappa = (float)kappa;
             l.weight = (float)(lb.w / wsum);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pgl_samples_destroy": (None, [C.c_void_p]),
     "pgl_samples_add_surface": (None, [C.c_void_p, _fp, _fp, _fp, C.c_int]),
     "pgl_field_update": (None, [C.c_void_p, C.c_void_p]),
+    "pt_pgl_samples_add_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "pgl_field_snapshot": (None, [C.c_void_p, C.POINTER(C.POINTER(PglRegion)), _u32p,
                                   C.POINTER(C.POINTER(PglLobe)), _u32p]),
     "pt_set_mode": (None, [C.c_int]),
@@ -297,6 +298,59 @@ def trace_rays(origins, dirs, tmin=None, tmax=None, any_hit=False):
     b2 = np.zeros(n, np.float32)
     lib().pt_trace_rays(n, _f(o), _f(d), _f(t0), _f(t1), 1 if any_hit else 0, _i(prim), _f(t), _f(b1), _f(b2))
     return prim, t, b1, b2
+
+
+def train_samples():
+    """The training ring of the last renders as an (n, 10) float32 array: position, dir_in, contrib, and the
+    is_delta flag as the bits of column 9 (the TrainSample layout, src/guiding.rs:5-11)."""
+    ptr = C.POINTER(TrainSample)()
+    cnt = C.c_uint32()
+    lib().guiding_map_train_samples(C.byref(ptr), C.byref(cnt))
+    if cnt.value == 0:
+        return np.zeros((0, 10), np.float32)
+    return np.ctypeslib.as_array(C.cast(ptr, _fp), shape=(cnt.value, 10)).copy()
+
+
+class GuidingField:
+    """RAII pair of a trainer device and a field with one reusable sample container (src/guiding.rs:71-143)."""
+
+    def __init__(self, scene_min, scene_max, threads=0):
+        L = lib()
+        self.dev = L.pgl_dev_create(threads)
+        mn, mx = np.asarray(scene_min, np.float32), np.asarray(scene_max, np.float32)
+        self.field = L.pgl_field_create(self.dev, _f(mn), _f(mx))
+        self.samples = L.pgl_samples_create()
+
+    def update(self, records):
+        """records: (n, 10) float32 in the TrainSample layout.  Adds them and updates the field."""
+        L = lib()
+        records = np.ascontiguousarray(records, np.float32)
+        if len(records):
+            L.pt_pgl_samples_add_batch(self.samples, records.ctypes.data_as(C.c_void_p), len(records))
+        L.pgl_field_update(self.field, self.samples)
+
+    def snapshot(self):
+        """(regions (n, 8) float32, lobes (m, 8) float32) in the layout upload_snapshot takes; the two integer
+        fields of a region are stored as float values."""
+        L = lib()
+        regs, lobes = C.POINTER(PglRegion)(), C.POINTER(PglLobe)()
+        nr, nl = C.c_uint32(), C.c_uint32()
+        L.pgl_field_snapshot(self.field, C.byref(regs), C.byref(nr), C.byref(lobes), C.byref(nl))
+        R = np.zeros((nr.value, 8), np.float32)
+        for i in range(nr.value):
+            R[i, 0:3], R[i, 3:6], R[i, 6], R[i, 7] = regs[i].bmin[:], regs[i].bmax[:], regs[i].lobe_ofs, regs[i].lobe_num
+        Lb = np.zeros((nl.value, 8), np.float32)
+        for i in range(nl.value):
+            Lb[i, 0:3], Lb[i, 3], Lb[i, 4], Lb[i, 5:8] = lobes[i].mu[:], lobes[i].kappa, lobes[i].weight, lobes[i].rgb[:]
+        return R, Lb
+
+    def close(self):
+        L = lib()
+        if self.samples:
+            L.pgl_samples_destroy(self.samples)
+            L.pgl_field_destroy(self.field)
+            L.pgl_dev_destroy(self.dev)
+            self.samples = self.field = self.dev = None
 
 
 def upload_snapshot(regions, lobes):

@@ -103,3 +103,57 @@ class DeviceSharedAdaptiveRenderer:
         torch.cuda.synchronize(self.device)  # stats was zeroed on torch's stream
         self.pt.render_adaptive_shared_device(stats, self.w, self.h, begin, count, total_spp, self.max_depth,
                                               self.frame, self.threshold, self.min_samples, reduce)
+
+
+class ShardedGuiding:
+    """The guiding loop of src/guiding.rs:222-247 for several GPUs.  The trainer keeps ONE field
+    (openpgl_bridge.cpp:47-58), so every rank's training ring is gathered on rank 0, which updates the field
+    and takes the snapshot; the snapshot is broadcast and every rank uploads it to its own renderer.
+
+    collect() returns this rank's records, (n, 10) float32 in the TrainSample layout; upload(regions, lobes)
+    installs a snapshot; reset() empties the ring.  The defaults are the library calls; tests pass stand-ins."""
+
+    def __init__(self, pt, scene_min, scene_max, group=None, collect=None, upload=None, reset=None):
+        self.pt, self.group = pt, group
+        self.many = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rank = dist.get_rank(group) if self.many else 0
+        self.world = dist.get_world_size(group) if self.many else 1
+        self.field = pt.GuidingField(scene_min, scene_max) if self.rank == 0 else None
+        self.collect = collect or pt.train_samples
+        self.upload = upload or pt.upload_snapshot
+        self.reset = reset or (lambda: pt.lib().guiding_reset_train_write_idx())
+
+    def process_batch(self):
+        """One update: gather, train on rank 0, broadcast, upload.  Returns (regions, lobes), the same on all ranks."""
+        local = torch.from_numpy(self.collect().astype("float32", copy=False).reshape(-1, 10).copy())
+        if self.many:
+            sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64), group=self.group)
+            longest = max(int(x) for x in sizes)
+            padded = torch.zeros((longest, 10), dtype=torch.float32)
+            padded[: local.shape[0]] = local
+            parts = [torch.zeros_like(padded) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(padded, parts, dst=0, group=self.group)
+            if self.rank == 0:
+                local = torch.cat([p[: int(n)] for p, n in zip(parts, sizes)])
+        if self.rank == 0:
+            self.field.update(local.numpy())
+            regions, lobes = self.field.snapshot()
+            shape = torch.tensor([regions.shape[0], lobes.shape[0]], dtype=torch.int64)
+        else:
+            shape = torch.zeros(2, dtype=torch.int64)
+        if self.many:
+            dist.broadcast(shape, src=0, group=self.group)
+            r = torch.from_numpy(regions) if self.rank == 0 else torch.zeros((int(shape[0]), 8), dtype=torch.float32)
+            l = torch.from_numpy(lobes) if self.rank == 0 else torch.zeros((int(shape[1]), 8), dtype=torch.float32)
+            dist.broadcast(r, src=0, group=self.group)
+            dist.broadcast(l, src=0, group=self.group)
+            regions, lobes = r.numpy(), l.numpy()
+        self.upload(regions, lobes)
+        self.reset()
+        return regions, lobes
+
+    def close(self):
+        if self.field is not None:
+            self.field.close()
+            self.field = None

@@ -448,6 +448,37 @@ def test_guided_render_parity(gpu, oracle, pipeline):
     assert abs(img.mean() - plain.mean()) / plain.mean() > 0.03
 
 
+def test_guiding_loop_through_the_helper(gpu):
+    """Render with the training ring on, train the stand-in field from the ring through the multi-GPU helper
+    (one rank here), upload the snapshot, render guided: the loop of src/main.rs:496-540."""
+    from ptamd import sharded
+    L = gpu.lib()
+    L.guiding_set_train_buffer_size(1 << 14)
+    L.guiding_set_grid_res(4, 4, 4)
+    try:
+        L.pt_set_frame(0)
+        plain = gpu.render_rgb(48, 36, 64)  # new resolution -> renderer with a ring
+        rec = gpu.train_samples()
+        assert 0.9 * (1 << 14) < len(rec) <= (1 << 14) and (rec[:, 9].view(np.uint32) == 0).all()
+        g = sharded.ShardedGuiding(gpu, (-1, -1, 0), (1, 1, 2))
+        regions, lobes = g.process_batch()
+        g.close()
+        assert len(regions) >= 1 and len(lobes) >= len(regions) and len(gpu.train_samples()) == 0
+        L.guiding_set_enabled(1)
+        L.pt_set_frame(0)
+        guided = gpu.render_rgb(48, 36, 64)
+        assert np.isfinite(guided).all() and not np.array_equal(guided, plain)
+        # the reference's guided branch is biased (it multiplies the throughput by the lobe colour, < 1 here):
+        # darker, not broken
+        assert 0.2 < guided.mean() / plain.mean() < 1.5
+    finally:
+        L.guiding_set_enabled(0)
+        L.guiding_set_train_buffer_size(0)
+        L.guiding_set_grid_res(1, 1, 1)
+        gpu.upload_snapshot(np.zeros((0, 8), np.float32), np.zeros((0, 8), np.float32))
+        gpu.render_rgb(44, 28, 1)  # a renderer without a ring for the tests that follow
+
+
 def test_train_sample_ring(gpu):
     """optix_device.cu:431-441 + optix_wrapper.cpp:1270-1294.  Vertices go to hashed ring slots (no shared
     counter in the render's inner loop), so a render with several times more vertices than slots fills

@@ -646,3 +646,67 @@ def test_obj_round_trip_is_exact(pt, tmp_path):
             assert a.shape == b.shape and np.array_equal(a, b)
     finally:
         L.pt_scene_cornell()
+
+
+# ------------------------------------------------------------------ guiding across ranks (gloo)
+_GUIDE_WORKER = r'''
+import sys
+import numpy as np, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import ptamd
+from ptamd import sharded
+rank = int(sys.argv[3])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=2)
+rng = np.random.default_rng(rank)
+n = 3000 + 1000 * rank  # rings of different lengths
+rec = np.zeros((n, 10), np.float32)
+rec[:, 0:2] = rng.uniform(-1, 1, (n, 2)); rec[:, 2] = rng.uniform(0, 2, n)
+d = rng.normal(size=(n, 3)) * 0.05
+d[:, 2] += 1.0 if rank == 0 else -1.0  # rank 0 sees light from above, rank 1 from below
+rec[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+rec[:, 6:9] = 1.0
+got = {}
+g = sharded.ShardedGuiding(ptamd, (-1, -1, 0), (1, 1, 2), collect=lambda: rec,
+                           upload=lambda r, l: got.update(regions=r.copy(), lobes=l.copy()), reset=lambda: got.update(reset=True))
+regions, lobes = g.process_batch()
+g.close()
+assert got["reset"] and np.array_equal(got["regions"], regions)
+np.savez(sys.argv[4] + "/g%d.npz" % rank, regions=regions, lobes=lobes)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_guiding_across_two_ranks(pt, tmp_path):
+    """src/guiding.rs:222-247 with two ranks: both rings reach the one field on rank 0, and both ranks end up
+    with the same snapshot, which holds what either rank saw (one lobe up, one lobe down)."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    script = tmp_path / "guide_worker.py"
+    script.write_text(_GUIDE_WORKER)
+    pkg = os.path.join(ROOT, "rust-pathtracer_amd")
+    procs = [subprocess.Popen([sys.executable, str(script), pkg, str(port), str(r), str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b = (np.load(tmp_path / f"g{r}.npz") for r in range(2))
+    assert np.array_equal(a["regions"], b["regions"]) and np.array_equal(a["lobes"], b["lobes"])
+    regions, lobes = a["regions"], a["lobes"]
+    assert len(regions) >= 1 and len(lobes) >= 2
+    assert regions[:, 6].astype(int).tolist() == np.concatenate([[0], np.cumsum(regions[:-1, 7])]).astype(int).tolist()
+    up = lobes[(lobes[:, 2] > 0.9) & (lobes[:, 4] > 0.2)]
+    down = lobes[(lobes[:, 2] < -0.9) & (lobes[:, 4] > 0.2)]
+    assert len(up) >= 1 and len(down) >= 1  # the field was trained on the union of the two rings
+    # one rank alone (no process group): the same calls, no collective
+    from ptamd import sharded
+    rec = np.zeros((500, 10), np.float32)
+    rec[:, 5] = 1.0
+    rec[:, 6:9] = 1.0
+    seen = {}
+    g = sharded.ShardedGuiding(pt, (-1, -1, 0), (1, 1, 2), collect=lambda: rec, upload=lambda r, l: seen.update(l=l),
+                               reset=lambda: None)
+    r1, l1 = g.process_batch()
+    g.close()
+    assert len(l1) >= 1 and seen["l"] is l1 and l1[np.argmax(l1[:, 4]), 2] > 0.9
