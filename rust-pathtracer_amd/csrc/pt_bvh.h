@@ -285,7 +285,7 @@ PT_HD uint32_t intersect_children_wide(const u4* n, const RayBox& rb, float tmin
   const u4* ny = n + (py ? 6 : 12), *fy = n + (py ? 12 : 6);
   const u4* nz = n + (pz ? 8 : 14), *fz = n + (pz ? 14 : 8);
   uint32_t mask = 0;
-#pragma unroll
+#pragma unroll 1
   for (int half = 0; half < 2; ++half) {
     const u4 w = n[2 + half];
     const u4 ax = nx[half], bxw = fx[half], ay = ny[half], byw = fy[half], az = nz[half], bzw = fz[half];

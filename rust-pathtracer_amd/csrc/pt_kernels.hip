@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
 // compact == 0: the queue is processed in place -- finished pixels stay in it and cost one
 // state read per launch -- and the other queue's counter is cleared for the next compaction.
 #ifndef PT_BOUNCE_WAVES
-#define PT_BOUNCE_WAVES 3
+#define PT_BOUNCE_WAVES 4
 #endif
 // Small scenes: nodes (unpacked, pt_bvh.h), item records and shading records are staged in LDS behind the
 // traversal stacks, so the divergent 16-byte gathers of traversal and shading never leave the CU.  Returns
