@@ -156,7 +156,7 @@ def main():
                          "bytes_per_ray": BYTES_PER_RAY},
             "roofline_valu": {"bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved_tflops / VALU_PEAK_TFLOPS, "flop_per_ray": FLOP_PER_RAY,
-                              "pmc_valu_pipe_busy": pmc.get("valu_pipe_busy"),
+                              "pmc_simd_cycles_per_valu_inst": pmc.get("simd_cycles_per_valu_inst"),
                               "pmc_lane_utilisation": pmc.get("valu_lane_utilisation"),
                               "pmc_valu_insts_per_ray": pmc.get("valu_insts_per_ray")},
         }

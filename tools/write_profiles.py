@@ -56,10 +56,9 @@ json.dump({"fused": {
     "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
     "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE as reported",
     "workload": f"cornell_1920x1080_1024spp_depth32_converge, {tot['FETCH_SIZE'][2]} launches of k_bounce_defer",
-    # SQ_ACTIVE_INST_VALU (quad-cycles) over the quad-cycles the SIMDs had; the two come from different passes
-    # and the clock is taken as 2.4 GHz, so a saturated pipe can read slightly above 1
-    "valu_pipe_busy": min(1.0, tot['SQ_ACTIVE_INST_VALU'][0] / avail),
-    "valu_pipe_busy_raw": tot['SQ_ACTIVE_INST_VALU'][0] / avail,
+    # SIMD cycles that went by per VALU wave-instruction issued (GRBM_GUI_ACTIVE is summed over the 8 XCDs;
+    # 1024 SIMDs).  A full 64-lane fp32 instruction occupies the SIMD for 4.
+    "simd_cycles_per_valu_inst": 1024 * (tot['GRBM_GUI_ACTIVE'][0] / 8) / tot['SQ_INSTS_VALU'][0],
     "valu_lane_utilisation": tot['SQ_THREAD_CYCLES_VALU'][0] / tot['SQ_INSTS_VALU'][0] / 64,
     "valu_insts_per_ray": tot['SQ_INSTS_VALU'][0] / rays_per_step,
     "source": "profiles/r01_pmc_fused.txt (rocprofv3 --pmc, one pass per counter group)"}}, open('profiles/pmc_traffic.json', 'w'), indent=1)
