@@ -169,6 +169,24 @@ PT_EXPORT int  pt_get_frame(void);
  * per-pixel PCG stream, so G chunks on one GPU equal G ranks with one chunk each. */
 PT_EXPORT int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth,
                                           int frame, float* d_sum_rgb);
+/* pt_render_accumulate_device for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+ * result bit for bit (same scene, default camera, fused pipeline), but every byte of device memory besides
+ * d_sum_rgb -- path state, slot queues, counters, the scene -- lives in one static array of the library's code
+ * object (PT_NOALLOC_MAX_SLOTS * 92 + PT_NOALLOC_MAX_SCENE_BYTES + 512 bytes = 24.2 MB, held by every GPU the
+ * library is loaded on until the process ends), and the call makes no hipMalloc / hipFree / hipHostMalloc /
+ * stream or event creation: work runs on the null stream, the live-slot counter is read back with a blocking
+ * copy after every batch of launches.  Limits: w * h * chunks <= PT_NOALLOC_MAX_SLOTS, where chunks is what
+ * pt_render_accumulate_device would use (min(16, 8388608 / (w*h)), lowered until every chunk has 32 samples, so
+ * 1 for sample_count < 64); the scene's BVH nodes, leaf items and shading records together at most
+ * PT_NOALLOC_MAX_SCENE_BYTES (the built-in scene: 3.6 KB); guiding off.  Returns 0, -1 for a NULL output, -2
+ * with the reason on stderr when a limit is exceeded (nothing is rendered then).  Every call on a GPU uses
+ * that GPU's one array: calls that overlap on the same GPU (two host threads, two processes do not share it)
+ * race; the array keeps the previous call's contents and the call clears what it needs. */
+#define PT_NOALLOC_MAX_SLOTS (1u << 18)
+#define PT_NOALLOC_MAX_SCENE_BYTES (64u << 10)
+PT_EXPORT int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int sample_count, int max_depth,
+                                                  int frame, float* d_sum_rgb);
 /* The same with adaptive sampling: this share's samples stop per pixel by the noise test run on the
  * share's own statistics (noise_threshold <= 0: fixed count).  ADDS the sums into d_sum_rgb (w*h*3) and
  * the number of samples each pixel took into d_count (w*h floats), both device pointers, caller-zeroed;

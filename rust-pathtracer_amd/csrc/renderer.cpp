@@ -127,14 +127,18 @@ void set_camera(State& s, const float eye[3], const float lookat[3], const float
 BvhBuildResult g_bvh;
 uint64_t g_bvh_version = 0;
 
-void upload_scene(State& s) {
+// The current scene's tree (built on first use per scene version) and its per-primitive shading records.
+const BvhBuildResult& current_bvh() {
   HostScene& hs = scene();
-  const int nt = hs.num_tris();
   if (g_bvh_version != g_scene_version) {
-    g_bvh = build_bvh8(hs.vertices.data(), hs.indices.data(), nt);
+    g_bvh = build_bvh8(hs.vertices.data(), hs.indices.data(), hs.num_tris());
     g_bvh_version = g_scene_version;
   }
-  const BvhBuildResult& bvh = g_bvh;
+  return g_bvh;
+}
+std::vector<ShadeRec> shade_records(const BvhBuildResult& bvh) {
+  HostScene& hs = scene();
+  const int nt = hs.num_tris();
   std::vector<ShadeRec> recs((size_t)std::max(nt, 1));
   memset(recs.data(), 0, recs.size() * sizeof(ShadeRec));
   for (int i = 0; i < nt; ++i) {
@@ -160,12 +164,13 @@ void upload_scene(State& s) {
     r.ior = m.ior;
     r.transmission = m.transmission;
   }
-  upload(s.d_nodes, bvh.nodes);
-  upload(s.d_tris, bvh.tris);
-  upload(s.d_shade, recs);
-  s.scene.nodes = s.d_nodes;
-  s.scene.tris = s.d_tris;
-  s.scene.shade = s.d_shade;
+  return recs;
+}
+
+// Fill in everything of State::scene but the three device pointers.
+void describe_scene(State& s, const BvhBuildResult& bvh) {
+  HostScene& hs = scene();
+  const int nt = hs.num_tris();
   s.scene.num_tris = (uint32_t)nt;
   s.scene.num_items = (uint32_t)bvh.num_items;
   s.scene.vmag = bvh.vmag;
@@ -180,6 +185,18 @@ void upload_scene(State& s) {
   s.num_nodes = (int)bvh.nodes.size();
   s.bvh_bytes = bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(q4);
   s.scene_version = g_scene_version;
+}
+
+void upload_scene(State& s) {
+  const BvhBuildResult& bvh = current_bvh();
+  const std::vector<ShadeRec> recs = shade_records(bvh);
+  upload(s.d_nodes, bvh.nodes);
+  upload(s.d_tris, bvh.tris);
+  upload(s.d_shade, recs);
+  s.scene.nodes = s.d_nodes;
+  s.scene.tris = s.d_tris;
+  s.scene.shade = s.d_shade;
+  describe_scene(s, bvh);
 }
 
 // optix_wrapper.cpp:1168-1253: convert the snapshot, build the region grid on the host, upload.
@@ -234,6 +251,12 @@ void upload_guide(State& s) {
   s.guide_valid = nl > 0;
 }
 
+// Chunks (slots per pixel) a renderer of px pixels has room for.
+int max_chunks_for(size_t px) {
+  static const size_t target_slots = getenv("PT_TARGET_SLOTS") ? (size_t)atoll(getenv("PT_TARGET_SLOTS")) : kTargetSlots;
+  return (int)std::max<size_t>(1, std::min<size_t>(16, target_slots / std::max<size_t>(px, 1)));
+}
+
 // optix_wrapper.cpp:784-920
 State* make_state(int W, int H) {
   State* s = new State();
@@ -252,8 +275,7 @@ State* make_state(int W, int H) {
   const size_t px = (size_t)W * (size_t)H;
   // A pixel's sample range may be rendered as several chunks side by side (one slot each);
   // state is sized for the most chunks a render of this resolution will use.
-  static const size_t target_slots = getenv("PT_TARGET_SLOTS") ? (size_t)atoll(getenv("PT_TARGET_SLOTS")) : kTargetSlots;
-  s->max_chunks = (int)std::max<size_t>(1, std::min<size_t>(16, target_slots / std::max<size_t>(px, 1)));
+  s->max_chunks = max_chunks_for(px);
   const size_t slots = px * (size_t)s->max_chunks;
   s->st_o = dev_alloc<q4>(slots); s->st_d = dev_alloc<q4>(slots); s->st_s = dev_alloc<q4>(slots);
   s->st_m = dev_alloc<u4>(slots); s->acc = dev_alloc<q4>(slots); s->hits = dev_alloc<q4>(slots);
@@ -410,6 +432,10 @@ struct RenderLoop {
     // launch overhead; the fused kernel then finishes the stragglers, many bounces per launch.  Both
     // pipelines work on the same state and give the same bits.
     tail_fused = chosen < 0 && !fused;
+    if (s.borrowed) {  // no hit / shadow records exist: the fused kernels only
+      fused = true;
+      tail_fused = false;
+    }
   }
 
   // Clear the per-slot state of a new render.
@@ -432,11 +458,12 @@ struct RenderLoop {
     static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
     bool use_fused = fused;
     int qin = 0, slot = 0;
+    int live[2] = {0, 0};  // per read-back slot: the queue that held the live slots when it was taken
     bool have_prev = false;
     for (;;) {
       const int iters_per_batch = use_fused ? 8 : 16;
       for (int b = 0; b < iters_per_batch; ++b, ++iter) {
-        const bool timed = g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
+        const bool timed = !s.borrowed && g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
         if (use_fused) {
           // compact the slot queue on the last launch of a batch only: finished slots are rare
           const int compact = (b == iters_per_batch - 1) ? 1 : 0;
@@ -451,27 +478,38 @@ struct RenderLoop {
         { Timer t(s, PT_K_OCCLUDE, timed, 0); launch_occlude(p, qin ^ 1, cfg); }
         qin ^= 1;
       }
+      // Only the counter of the queue the next launch reads says how many slots are live: the other one
+      // still holds the previous length until a later launch clears it.
+      if (s.borrowed) {  // no pinned memory and no events: a blocking copy after every batch
+        uint32_t c[CNT_WORDS];
+        HIP_CHECK(hipMemcpy(c, s.counters, sizeof(c), hipMemcpyDeviceToHost));
+        if (c[qin] == 0u) break;
+        continue;
+      }
       HIP_CHECK(hipMemcpyAsync(s.h_counters + slot * CNT_WORDS, s.counters, CNT_WORDS * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, s.stream));
       HIP_CHECK(hipEventRecord(s.ev_slot[slot], s.stream));
+      live[slot] = qin;
       if (have_prev) {
         const int prev = slot ^ 1;
         HIP_CHECK(hipEventSynchronize(s.ev_slot[prev]));
-        const uint32_t* c = s.h_counters + prev * CNT_WORDS;
-        if (c[CNT_Q0] + c[CNT_Q1] == 0u) break;
-        if (tail_fused && c[CNT_Q0] + c[CNT_Q1] < n / 16u) use_fused = true;
+        const uint32_t left = s.h_counters[prev * CNT_WORDS + live[prev]];
+        if (left == 0u) break;
+        if (tail_fused && left < n / 16u) use_fused = true;
       }
       have_prev = true;
       slot ^= 1;
     }
   }
 
-  void begin() { HIP_CHECK(hipEventRecord(s.ev_begin, s.stream)); }
+  void begin() {
+    if (!s.borrowed) HIP_CHECK(hipEventRecord(s.ev_begin, s.stream));
+  }
   void end() {
-    HIP_CHECK(hipEventRecord(s.ev_end, s.stream));
+    if (!s.borrowed) HIP_CHECK(hipEventRecord(s.ev_end, s.stream));
     HIP_CHECK(hipStreamSynchronize(s.stream));
     float ms = 0.f;
-    HIP_CHECK(hipEventElapsedTime(&ms, s.ev_begin, s.ev_end));
+    if (!s.borrowed) HIP_CHECK(hipEventElapsedTime(&ms, s.ev_begin, s.ev_end));
     s.last_render_ms = ms;
     resolve_timers(s);
     unsigned long long rc[2];
@@ -482,16 +520,19 @@ struct RenderLoop {
   }
 };
 
-void render_core(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
-  RenderLoop loop(s, make_params(s, sample_begin, sample_count, max_depth, frame, strict));
+void render_core(State& s, const RenderParams& params) {
+  RenderLoop loop(s, params);
   s.last_chunks = loop.p.chunks;
   s.adaptive_rounds = 0;
   const size_t slots = (size_t)loop.p.npx * (size_t)loop.p.chunks;
   loop.begin();
   loop.reset_slots();
   launch_iota(s.queue[0], (uint32_t)slots, s.stream);
-  if (sample_count > 0) loop.drain((uint32_t)slots);
+  if (params.sample_count > 0) loop.drain((uint32_t)slots);
   loop.end();
+}
+void render_core(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
+  render_core(s, make_params(s, sample_begin, sample_count, max_depth, frame, strict));
 }
 
 // Adaptive sampling (optix_wrapper.cpp:1002-1021 with optix_device.cu:1011-1060), made independent of
@@ -635,9 +676,73 @@ struct DevBuf {
 };
 State& dbg_state() { return ensure_handle(g_last_w > 0 ? g_last_w : 16, g_last_h > 0 ? g_last_h : 16); }
 
+// ---- allocation-free rendering (pt_render_accumulate_device_noalloc)
+// All device memory the render needs besides the caller's output -- path state, slot queues, counters and
+// the scene -- lives in one array of the library's code object, so the call never touches the allocator.
+// Each GPU the library runs on holds its own copy of the array from the moment the code object is loaded
+// there until the process ends.
+constexpr size_t kNaMaxSlots = PT_NOALLOC_MAX_SLOTS;
+constexpr size_t kNaMaxSceneBytes = PT_NOALLOC_MAX_SCENE_BYTES;
+constexpr size_t kNaSmall = 256;  // counters, ray counters: one aligned line each
+// per slot: origin, direction, sample sum, rng/flags, finished-sample sum (16 B each), samples started, two queues
+constexpr size_t kNaScratchBytes = kNaMaxSlots * (5 * 16 + 4 + 2 * 4) + kNaMaxSceneBytes + 2 * kNaSmall;
+static __device__ __align__(256) unsigned char scratch[kNaScratchBytes];
+
+struct NoAllocDevice {
+  bool ready = false;
+  unsigned char* base = nullptr;  // device address of `scratch` on this GPU
+  unsigned char* scene_mem = nullptr;
+  State state;
+  uint32_t h_counters[3 * CNT_WORDS] = {0};
+};
+constexpr int kNaMaxDevices = 64;
+NoAllocDevice g_noalloc[kNaMaxDevices];
+
+// First call on a device (that device current): find this GPU's copy of the array and carve it up.
+NoAllocDevice& noalloc_device(int device) {
+  NoAllocDevice& na = g_noalloc[device];
+  if (na.ready) return na;
+  void* ptr = nullptr;
+  HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  na.base = static_cast<unsigned char*>(ptr);
+  unsigned char* cur = na.base;
+  auto take = [&](size_t bytes) {
+    unsigned char* r = cur;
+    cur += (bytes + 255u) & ~(size_t)255u;
+    return r;
+  };
+  State& s = na.state;
+  s.borrowed = true;
+  s.device = device;
+  s.stream = nullptr;  // the null stream: creating one would allocate
+  s.st_o = reinterpret_cast<q4*>(take(kNaMaxSlots * 16));
+  s.st_d = reinterpret_cast<q4*>(take(kNaMaxSlots * 16));
+  s.st_s = reinterpret_cast<q4*>(take(kNaMaxSlots * 16));
+  s.st_m = reinterpret_cast<u4*>(take(kNaMaxSlots * 16));
+  s.acc = reinterpret_cast<q4*>(take(kNaMaxSlots * 16));
+  s.started = reinterpret_cast<int*>(take(kNaMaxSlots * 4));
+  s.queue[0] = reinterpret_cast<uint32_t*>(take(kNaMaxSlots * 4));
+  s.queue[1] = reinterpret_cast<uint32_t*>(take(kNaMaxSlots * 4));
+  s.counters = reinterpret_cast<uint32_t*>(take(kNaSmall));
+  s.ray_counters = reinterpret_cast<unsigned long long*>(take(kNaSmall));
+  na.scene_mem = take(kNaMaxSceneBytes);
+  if ((size_t)(cur - na.base) > kNaScratchBytes) {
+    fprintf(stderr, "[pt_hip] internal error: scratch layout exceeds the array\n");
+    std::abort();
+  }
+  s.h_counters = na.h_counters;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_CHECK(hipMemsetAsync(s.ray_counters, 0, 2 * sizeof(unsigned long long), s.stream));
+  na.ready = true;
+  return na;
+}
+
 }  // namespace
 
 State::~State() {
+  if (borrowed) return;  // nothing here is this State's to release
   if (stream) (void)hipStreamSynchronize(stream);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   for (TimedLaunch& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -792,6 +897,73 @@ int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count
   if (!d_sum_rgb) return -1;
   render_core(s, sample_begin, sample_count, max_depth, frame, false);
   launch_finalize(s.acc, s.started, d_sum_rgb, (uint32_t)((size_t)w * (size_t)h), s.last_chunks, 1, s.stream);
+  HIP_CHECK(hipStreamSynchronize(s.stream));
+  return 0;
+}
+
+int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int sample_count, int max_depth, int frame,
+                                        float* d_sum_rgb) {
+  if (!d_sum_rgb) return -1;
+  const int device = device_index();
+  if (w <= 0 || h <= 0 || sample_count < 0 || device < 0 || device >= kNaMaxDevices) {
+    fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: bad argument (w %d, h %d, samples %d, device %d)\n", w, h,
+            sample_count, device);
+    return -2;
+  }
+  HIP_CHECK(hipSetDevice(device));
+  NoAllocDevice& na = noalloc_device(device);
+  State& s = na.state;
+  const size_t px = (size_t)w * (size_t)h;
+  if (px > kNaMaxSlots) {
+    fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: %d x %d = %zu pixels exceed the scratch array's %zu path slots\n",
+            w, h, px, kNaMaxSlots);
+    return -2;
+  }
+  if (g_guiding_enabled && !g_snap_regions.empty()) {
+    fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: guided sampling needs the field in device memory "
+                    "(use pt_render_accumulate_device, or guiding_set_enabled(0))\n");
+    return -2;
+  }
+  // scene: small scenes only, copied into the array when the scene has changed
+  const BvhBuildResult& bvh = current_bvh();
+  const size_t nodes_b = (bvh.nodes.size() * sizeof(BvhNode) + 255u) & ~(size_t)255u;
+  const size_t tris_b = (bvh.tris.size() * sizeof(q4) + 255u) & ~(size_t)255u;
+  const size_t shade_b = (size_t)std::max(scene().num_tris(), 1) * sizeof(ShadeRec);
+  if (nodes_b + tris_b + shade_b > kNaMaxSceneBytes) {
+    fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: the scene (%zu bytes of nodes, items and shading records) "
+                    "exceeds the %zu bytes reserved for it\n", nodes_b + tris_b + shade_b, kNaMaxSceneBytes);
+    return -2;
+  }
+  if (s.scene_version != g_scene_version) {
+    const std::vector<ShadeRec> recs = shade_records(bvh);
+    BvhNode* dn = reinterpret_cast<BvhNode*>(na.scene_mem);
+    q4* dt = reinterpret_cast<q4*>(na.scene_mem + nodes_b);
+    ShadeRec* ds = reinterpret_cast<ShadeRec*>(na.scene_mem + nodes_b + tris_b);
+    HIP_CHECK(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(q4), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(ds, recs.data(), recs.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
+    s.scene.nodes = dn;
+    s.scene.tris = dt;
+    s.scene.shade = ds;
+    describe_scene(s, bvh);
+  }
+  s.width = w;
+  s.height = h;
+  s.max_chunks = max_chunks_for(px);  // the same split into chunks as pt_render_accumulate_device ...
+  const float eye[3] = {0.f, 3.f, 1.f}, look[3] = {0.f, 0.f, 1.f}, up[3] = {0.f, 0.f, 1.f};
+  set_camera(s, eye, look, up, 45.f);
+  RenderParams p = make_params(s, sample_begin, sample_count, max_depth, frame, false);
+  p.guiding = 0;
+  p.train = nullptr;
+  p.train_write_idx = nullptr;
+  p.train_capacity = 0;
+  if (px * (size_t)p.chunks > kNaMaxSlots) {  // ... so the two agree bit for bit; more than fit: refuse
+    fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: %d x %d pixels in %d chunks of samples = %zu path slots "
+                    "exceed the scratch array's %zu\n", w, h, p.chunks, px * (size_t)p.chunks, kNaMaxSlots);
+    return -2;
+  }
+  render_core(s, p);
+  launch_finalize(s.acc, s.started, d_sum_rgb, (uint32_t)px, s.last_chunks, 1, s.stream);
   HIP_CHECK(hipStreamSynchronize(s.stream));
   return 0;
 }

@@ -91,6 +91,11 @@ struct State {
   std::vector<TimedLaunch> timed;
   double last_render_ms = 0.0;
 
+  // true: every device pointer above points into memory this State does not own (the allocation-free entry
+  // point's scratch array), work runs on the null stream, h_counters is ordinary host memory and there are no
+  // events; the destructor then releases nothing.
+  bool borrowed = false;
+
   ~State();
 };
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "pt_set_frame": (None, [C.c_int]),
     "pt_get_frame": (C.c_int, []),
     "pt_render_accumulate_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pt_render_accumulate_device_noalloc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pt_render_adaptive_accumulate_device": (C.c_int, [C.c_int] * 6 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "pt_render_adaptive_shared_device": (C.c_int, [C.c_int] * 7 + [C.c_float, C.c_int, C.c_void_p, REDUCE_FN, C.c_void_p]),
     "pt_mosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
