@@ -115,7 +115,7 @@ PT_HD bool intersect_triangle(const RayShear& rs, f3 o, f3 v0, f3 v1, f3 v2, flo
 constexpr int kTriWords = 4;
 
 // Fast ray/triangle test: solve for t on the plane, evaluate the barycentrics directly.  It decides
-// alone only when the hit point is clearly inside or clearly outside; a point within the error band
+// alone when the hit point is clearly inside or clearly outside; a point within the error band
 // of an edge goes to the watertight test on the original vertices (intersect_triangle), so shared
 // edges and vertices keep the watertight test's answer and no ray slips between two triangles.
 // Returns 0 miss, 1 hit (hit updated), 2 undecided.
@@ -128,10 +128,10 @@ PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, 
   const f3 A = o - ldq(q0);
   const f3 n = ldq(q3);
   const float t = -shear_dot(n, A) * rcp(shear_dot(n, d));  // parallel ray: t is inf or nan and the next test fails
-  // slack: a few ulps of the coordinates involved.  A ray that starts on the plane itself (t ~ tmin) is
-  // the watertight test's call too: its answer there is decided by its own rounding.
-  const float slack = 9.5367431640625e-7f * (rmag + fabsf(t));
-  if (!(t + slack > tmin) || !(t - slack < hit.t)) return 0;
+  // The interval test is exact on this t.  A ray that starts on the plane itself (the reference's 1e-3 offset puts
+  // a path that leaves the glass box through its bottom face exactly on the floor) has t = +-1e-9: which side it
+  // falls on is rounding noise in any formulation, so this one's sign decides and no second opinion is asked for.
+  if (!(t > tmin) || !(t < hit.t)) return 0;
   const f3 r1 = ldq(q1), r2 = ldq(q2);
   float b1 = __builtin_fmaf(t, shear_dot(r1, d), shear_dot(r1, A));
   float b2 = __builtin_fmaf(t, shear_dot(r2, d), shear_dot(r2, A));
@@ -147,8 +147,7 @@ PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, 
     prim = f2u(q3.w);
   }
   if (!(lo >= -eps)) return 0;
-  if (lo <= eps || t - slack <= tmin) return 2;
-  if (!(t < hit.t)) return 0;
+  if (lo <= eps) return 2;
   hit.t = t;
   hit.b1 = b1;
   hit.b2 = b2;

@@ -465,8 +465,10 @@ struct RenderLoop {
       for (int b = 0; b < iters_per_batch; ++b, ++iter) {
         const bool timed = !s.borrowed && g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
         if (use_fused) {
-          // compact the slot queue on the last launch of a batch only: finished slots are rare
-          const int compact = (b == iters_per_batch - 1) ? 1 : 0;
+          // compact the slot queue every compact_every launches (a divisor of the batch length)
+          // (at least 2: a launch that does not compact clears the counter the next compaction appends to)
+          static const int compact_every = getenv("PT_COMPACT_EVERY") ? std::max(atoi(getenv("PT_COMPACT_EVERY")), 2) : 8;
+          const int compact = ((b + 1) % compact_every == 0 || b == iters_per_batch - 1) ? 1 : 0;
           Timer t(s, PT_K_BOUNCE, timed, 0);
           launch_bounce(p, qin, std::max(fused_bounces, 1), compact, cfg_fused);
           if (compact) qin ^= 1;
