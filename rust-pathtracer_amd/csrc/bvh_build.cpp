@@ -575,15 +575,31 @@ struct Emitter {
       if (c < 0) {
         node.meta[s] = 0;
         for (int k = 0; k < 3; ++k) { qlo[k][s] = 255; qhi[k][s] = 0; }
+        if (!out.exact_bounds.empty())
+          for (int k = 0; k < 3; ++k) {
+            out.exact_bounds[48 * (size_t)out_index + 8 * k + s] = 255.0f;
+            out.exact_bounds[48 * (size_t)out_index + 24 + 8 * k + s] = 0.0f;
+          }
         continue;
       }
       const Node2& cn = b.nodes2[c];
       for (int k = 0; k < 3; ++k) {
         const double sc = std::ldexp(1.0, e[k]);
-        double lo = std::floor(((double)cn.box.lo[k] - (double)nb.lo[k]) / sc);
-        double hi = std::ceil(((double)cn.box.hi[k] - (double)nb.lo[k]) / sc);
+        const double glo = ((double)cn.box.lo[k] - (double)nb.lo[k]) / sc, ghi = ((double)cn.box.hi[k] - (double)nb.lo[k]) / sc;
+        double lo = std::floor(glo);
+        double hi = std::ceil(ghi);
         qlo[k][s] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
         qhi[k][s] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
+        if (!out.exact_bounds.empty()) {
+          // the same box, unquantised: widened by a few 1e-6 of the scene's size and rounded outwards
+          const double padg = 4e-6 * std::max((double)out.vmag, 1e-3) / sc;
+          float flo = (float)(glo - padg), fhi = (float)(ghi + padg);
+          if ((double)flo > glo - padg) flo = std::nextafterf(flo, -INFINITY);
+          if ((double)fhi < ghi + padg) fhi = std::nextafterf(fhi, INFINITY);
+          float* ex = out.exact_bounds.data() + 48 * (size_t)out_index;
+          ex[8 * k + s] = std::max(flo, (float)qlo[k][s]);        // never looser than the quantised box
+          ex[24 + 8 * k + s] = std::min(fhi, (float)qhi[k][s]);
+        }
       }
       if (cn.count == 0) {
         node.imask |= (uint8_t)(1u << s);
@@ -712,6 +728,7 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   em.below.assign(b.nodes2.size(), 0u);
   const uint32_t nodes_below_root = em.count_below(root2);
   out.nodes.resize(1 + (size_t)nodes_below_root);
+  if (out.nodes.size() <= kExactBoundsMaxNodes) out.exact_bounds.assign(48 * out.nodes.size(), 0.0f);
   out.depth = em.emit(0, root2, 1u, 0u);
   if (timing)
     fprintf(stderr, "bvh build: %d triangles in %d leaf items, binary tree %.2f s (%d threads), collapse %.2f s, emit %.2f s\n", num_tris, num_items,

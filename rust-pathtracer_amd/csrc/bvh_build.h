@@ -21,10 +21,17 @@ struct BvhBuildResult {
   // (bits 0-1: the input corner that comes first, ...); 0x24 = as given.  Barycentrics of a hit refer to
   // this order.
   std::vector<uint8_t> corner_order;
+  // Small trees only (at most kExactBoundsMaxNodes nodes, else empty): per node 48 floats, the child boxes in
+  // the node's grid units but NOT rounded to the 8-bit grid -- lo x, lo y, lo z, hi x, hi y, hi z, 8 slots each,
+  // padded outwards by a few ulps; an empty slot is (255, 0).  Kernels that unpack the nodes into LDS test these
+  // instead of the quantised boxes: same hits, fewer false candidates.
+  std::vector<float> exact_bounds;
   int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
   int num_tris = 0;
   int num_items = 0;           // leaf items: single triangles, or two triangles forming a parallelogram
 };
+
+constexpr size_t kExactBoundsMaxNodes = 96;
 
 // Whether consecutive triangles that form a parallelogram share one leaf item (default: yes, unless the
 // environment says PT_BVH_PAIRS=0); on < 0 returns to that default.  Applies to the next build.

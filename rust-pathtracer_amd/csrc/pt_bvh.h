@@ -273,6 +273,13 @@ PT_HD void unpack_node_slot(const BvhNode& nd, int j, uint32_t* w) {
   }
 }
 
+// Replace slot j's bounds in an unpacked node by the unquantised ones the builder kept for small trees
+// (BvhBuildResult::exact_bounds: 48 floats per node in the same order as words 16..63).  Boxes only get
+// tighter (never tighter than the child), so the hits are the same and fewer items are tested for nothing.
+PT_HD void unpack_exact_bounds(const float* ex, int j, uint32_t* w) {
+  for (int a = 0; a < 6; ++a) w[16 + 8 * a + j] = f2u(ex[8 * a + j]);
+}
+
 PT_HD uint32_t intersect_children_wide(const u4* n, const RayBox& rb, float tmin, float tmax) {
   const u4 ha = n[0], hb = n[1];
   const float sx = u2f(hb.x) * rb.idir.x, sy = u2f(hb.y) * rb.idir.y, sz = u2f(hb.z) * rb.idir.z;
@@ -343,6 +350,7 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
   int sp = 0;
   for (;;) {
     StackEntry tg;
+    PT_TIC(t_node);
     if (cur.bits & 0xff000000u) {
       PT_PROF(any_hit ? PF_SH_NODE : PF_NODE);
       const uint32_t hits_imask = cur.bits;
@@ -374,6 +382,8 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
       cur.base = 0u;
       cur.bits = 0u;
     }
+    PT_TOC(t_node, PT_T_NODE);
+    PT_TIC(t_tri);
     while (tg.bits) {
       PT_PROF(any_hit ? PF_SH_TRI : PF_TRI);
       const int ti = __builtin_ctz(tg.bits);
@@ -387,6 +397,7 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
       }
       if (res == 1 && any_hit) return hit;
     }
+    PT_TOC(t_tri, PT_T_TRI);
     if ((cur.bits & 0xff000000u) == 0u) {
       if (sp == 0) break;
       PT_PROF(any_hit ? PF_SH_POP : PF_POP);

@@ -396,8 +396,12 @@ __device__ __forceinline__ u4* stage_scene(const RenderParams& p, u4* dst, Scene
                  n_shade16 = p.scene.num_tris * 6u;
   const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
   const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
-  for (uint32_t k = threadIdx.x; k < p.scene_nodes * 8u; k += blockDim.x)
-    unpack_node_slot(p.scene.nodes[k >> 3], (int)(k & 7u), reinterpret_cast<uint32_t*>(dst + kWideNodeWords * (k >> 3)));
+  for (uint32_t k = threadIdx.x; k < p.scene_nodes * 8u; k += blockDim.x) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(dst + kWideNodeWords * (k >> 3));
+    const uint32_t j = k & 7u;
+    unpack_node_slot(p.scene.nodes[k >> 3], (int)j, w);
+    if (p.scene.exact) unpack_exact_bounds(p.scene.exact + 48u * (k >> 3), (int)j, w);  // small trees: unquantised boxes
+  }
   for (uint32_t k = threadIdx.x; k < n_tris16; k += blockDim.x) dst[n_nodes16 + k] = src_t[k];
   for (uint32_t k = threadIdx.x; k < n_shade16; k += blockDim.x) dst[n_nodes16 + n_tris16 + k] = src_s[k];
   __syncthreads();
@@ -546,6 +550,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
     const uint32_t origin = f2u(dq[7 * kDeferCap + e]);
     rays_sh++;
     PT_PROF(PF_SHADOW);
+    PT_TIC(t_sh);
     const Hit h = trace_ray(sc, o, d, 0.0f, tmax, true, st, p.stack_depth, origin);
     if (h.prim < 0) {
       const uint32_t owner = f2u(dq[11 * kDeferCap + e]);
@@ -553,6 +558,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
       atomicAdd(&late[64u + owner], dq[9 * kDeferCap + e]);
       atomicAdd(&late[128u + owner], dq[10 * kDeferCap + e]);
     }
+    PT_TOC(t_sh, PT_T_SHADOW);
   };
 
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
@@ -582,10 +588,12 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
     // its bounces made them, whatever else shares the wave, so a slot's result does not depend on
     // which slots it is grouped with (queue order after a compaction is not reproducible)
     uint32_t head = 0, waiting = 0;  // the same on every lane
+    PT_TIC(t_loop);
     for (int b = 0; b < bounces; ++b) {
       ShadowRay sr;
       sr.valid = false;
       if (active) { PT_PROF(PF_BOUNCE); }
+      PT_TIC(t_regen);
       if (active && !(ps.flags & kAlive)) {
         PT_PROF(PF_REGEN);
         if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's sum
@@ -603,14 +611,20 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
           local++;
         }
       }
+      PT_TOC(t_regen, PT_T_REGEN);
       if (active) {
         rc.s = hash_sample_index(p, sl, local - 1);
+        PT_TIC(t_trace);
         const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth, ps.origin);
+        PT_TOC(t_trace, PT_T_TRACE);
         rays_rad++;
         TrainVertex tv;
+        PT_TIC(t_shade);
         shade_hit<GUIDED, TRAIN>(sc, p.guide, sp, rc, ps, h, sr, tv);
         if (TRAIN) capture_train(p, tv, ps.seed, pixel, captured);
+        PT_TOC(t_shade, PT_T_SHADE);
       }
+      PT_TIC(t_enq);
       const unsigned long long made = __ballot(sr.valid);
       if (sr.valid) {
         const uint32_t e = (head + waiting + (uint32_t)__popcll(made & ((1ull << lane) - 1ull))) & (kDeferCap - 1u);
@@ -622,6 +636,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
         dq[11 * kDeferCap + e] = u2f(lane);
       }
       waiting += (uint32_t)__popcll(made);
+      PT_TOC(t_enq, PT_T_ENQUEUE);
       if (waiting >= 64u) {
         trace_deferred((head + lane) & (kDeferCap - 1u));
         head = (head + 64u) & (kDeferCap - 1u);
@@ -629,6 +644,8 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
       }
       if (__ballot(active) == 0ull) break;
     }
+    PT_TOC(t_loop, PT_T_LOOP);
+    PT_TIC(t_epi);
     if (lane < waiting) trace_deferred((head + lane) & (kDeferCap - 1u));  // flush what is left, at whatever occupancy
     if (entered) {
       const f3 add = mk3(late[lane], late[64u + lane], late[128u + lane]);
@@ -646,6 +663,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
       const uint32_t slot = wave_append_slot(keep, &p.counters[qin ^ 1]);
       if (keep) q_out[slot] = pixel;
     }
+    PT_TOC(t_epi, PT_T_EPILOGUE);
   }
 #ifdef PT_PROFILE
   __syncthreads();
@@ -870,7 +888,7 @@ int read_profile_counters(unsigned long long* out64) {
   unsigned long long zero[64] = {0};
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof_global), sizeof(zero)) != hipSuccess) return 0;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_global), zero, sizeof(zero)) != hipSuccess) return 0;
-  return PF_COUNT;
+  return 32;  // 18 section pairs, then PT_T_COUNT time sums from word 40
 #else
   (void)out64;
   return 0;

@@ -37,9 +37,22 @@ __shared__ unsigned int g_prof_lds[64];
       atomicAdd(&g_prof_lds[2 * (k) + 1], (unsigned)__popcll(m_));                       \
     }                                                                                    \
   } while (0)
+// Time sections: shader-clock ticks a wave spends between PT_TIC and PT_TOC(k), summed over waves into
+// g_prof_lds[40 + k].  (With several waves per SIMD a wave's ticks include the turns of its neighbours, so read
+// the sums as shares of the total, not as instruction counts.)
+#define PT_TIC(name) const unsigned long long name = __builtin_amdgcn_s_memtime()
+#define PT_TOC(name, k)                                                                  \
+  do {                                                                                   \
+    const unsigned long long d_ = __builtin_amdgcn_s_memtime() - name;                   \
+    const unsigned long long m_ = __ballot(1);                                           \
+    if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m_)) atomicAdd(&g_prof_lds[40 + (k)], (unsigned)d_); \
+  } while (0)
 #else
 #define PT_PROF(k) do { } while (0)
+#define PT_TIC(name) do { } while (0)
+#define PT_TOC(name, k) do { } while (0)
 #endif
+enum { PT_T_LOOP = 0, PT_T_REGEN, PT_T_TRACE, PT_T_SHADE, PT_T_ENQUEUE, PT_T_SHADOW, PT_T_EPILOGUE, PT_T_NODE, PT_T_TRI, PT_T_COUNT };
 // profiling sections
 enum { PF_BOUNCE = 0, PF_REGEN, PF_NODE, PF_TRI, PF_SHADE, PF_GLASS, PF_OPAQUE, PF_NEE, PF_SPEC, PF_DIFFUSE,
        PF_SH_NODE, PF_SH_TRI, PF_SHADOW, PF_POP, PF_SH_POP, PF_EMIS_MIS, PF_RR, PF_FALLBACK, PF_COUNT };
@@ -219,6 +232,7 @@ struct GuideView {
 struct SceneView {
   const BvhNode* nodes;
   const u4* wide;            // the same nodes unpacked (pt_bvh.h), or null: set by kernels that stage the scene in LDS
+  const float* exact;        // small trees: 48 unquantised child bounds per node in grid units (bvh_build.h), or null
   // 4 x q4 per leaf item (a triangle, or two forming a parallelogram) in BVH leaf order (see the record
   // layout in pt_bvh.h): v0 and the rows that map (p - v0) to the barycentrics of v1, v2 and to the distance
   // from the plane

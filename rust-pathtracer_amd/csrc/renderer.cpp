@@ -193,6 +193,8 @@ void upload_scene(State& s) {
   upload(s.d_nodes, bvh.nodes);
   upload(s.d_tris, bvh.tris);
   upload(s.d_shade, recs);
+  upload(s.d_exact, bvh.exact_bounds);
+  s.scene.exact = bvh.exact_bounds.empty() ? nullptr : s.d_exact;
   s.scene.nodes = s.d_nodes;
   s.scene.tris = s.d_tris;
   s.scene.shade = s.d_shade;
@@ -748,7 +750,7 @@ State::~State() {
   if (stream) (void)hipStreamSynchronize(stream);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   for (TimedLaunch& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-  dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade);
+  dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade); dev_free(d_exact);
   dev_free(st_o); dev_free(st_d); dev_free(st_s); dev_free(st_m); dev_free(acc); dev_free(hits);
   dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started);
   dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
@@ -930,10 +932,11 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
   const BvhBuildResult& bvh = current_bvh();
   const size_t nodes_b = (bvh.nodes.size() * sizeof(BvhNode) + 255u) & ~(size_t)255u;
   const size_t tris_b = (bvh.tris.size() * sizeof(q4) + 255u) & ~(size_t)255u;
-  const size_t shade_b = (size_t)std::max(scene().num_tris(), 1) * sizeof(ShadeRec);
-  if (nodes_b + tris_b + shade_b > kNaMaxSceneBytes) {
+  const size_t shade_b = ((size_t)std::max(scene().num_tris(), 1) * sizeof(ShadeRec) + 255u) & ~(size_t)255u;
+  const size_t exact_b = bvh.exact_bounds.size() * sizeof(float);
+  if (nodes_b + tris_b + shade_b + exact_b > kNaMaxSceneBytes) {
     fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: the scene (%zu bytes of nodes, items and shading records) "
-                    "exceeds the %zu bytes reserved for it\n", nodes_b + tris_b + shade_b, kNaMaxSceneBytes);
+                    "exceeds the %zu bytes reserved for it\n", nodes_b + tris_b + shade_b + exact_b, kNaMaxSceneBytes);
     return -2;
   }
   if (s.scene_version != g_scene_version) {
@@ -944,6 +947,9 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
     HIP_CHECK(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(q4), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(ds, recs.data(), recs.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
+    float* dx = reinterpret_cast<float*>(na.scene_mem + nodes_b + tris_b + shade_b);
+    if (exact_b) HIP_CHECK(hipMemcpy(dx, bvh.exact_bounds.data(), exact_b, hipMemcpyHostToDevice));
+    s.scene.exact = exact_b ? dx : nullptr;
     s.scene.nodes = dn;
     s.scene.tris = dt;
     s.scene.shade = ds;

@@ -48,6 +48,7 @@ struct State {
   BvhNode* d_nodes = nullptr;
   q4* d_tris = nullptr;
   ShadeRec* d_shade = nullptr;
+  float* d_exact = nullptr;  // unquantised child bounds of a small tree (BvhBuildResult::exact_bounds)
   SceneView scene{};
   int bvh_depth = 1, num_nodes = 0;
   size_t bvh_bytes = 0;

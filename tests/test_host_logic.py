@@ -237,6 +237,53 @@ def test_unpacked_nodes_traverse_like_packed_ones(hostcheck):
         hostcheck.hc_scene_cornell()
 
 
+def test_unquantised_bounds_give_the_same_hits(hostcheck):
+    """Small trees keep their child boxes unquantised for the kernels that unpack nodes into LDS: tighter boxes,
+    so fewer candidates, but every hit (primitive, distance, barycentrics, occlusion) is the packed tree's,
+    bit for bit -- including rays aimed at edges and corners of the closed box."""
+    import geom_cases
+    rng = np.random.default_rng(11)
+
+    def both(o, d, want_exact=True):
+        assert hostcheck.hc_has_exact_bounds() == (1 if want_exact else 0)
+        out = []
+        tmax = rng.uniform(0.2, 4.0, len(o)).astype(np.float32)
+        for mode in (0, 2):
+            hostcheck.hc_set_wide_nodes(mode)
+            out.append(_hc_trace(hostcheck, o, d) + (_hc_trace(hostcheck, o, d, tmax, any_hit=1)[0],))
+        hostcheck.hc_set_wide_nodes(0)
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+
+    try:
+        hostcheck.hc_scene_cornell()
+        both(*_random_rays(40000, 6))
+        # rays from inside the room at points on edges, corners and quad diagonals
+        targets = []
+        for s in np.linspace(-1, 0.95, 60):
+            targets += [(s, s, 0.0), (s, -1.0, 1.0 + s), (-1.0, s, 1.0 - s), (1.0, s, 1.0 + s), (s, -s, 2.0),
+                        (s, -1.0, 0.0), (-1.0, -1.0, 1.0 + s), (1.0, -1.0, 1.0 + s), (s, s, 2.0)]
+        targets = np.array(targets, np.float32)
+        org = np.tile(np.array([[0.123, 0.3, 1.1]], np.float32), (len(targets), 1))
+        d = targets - org
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        both(org, d.astype(np.float32))
+        prim = _hc_trace(hostcheck, org, d.astype(np.float32))[0]
+        assert (prim >= 0).all()
+        hostcheck.hc_scene_synthetic(7, 2, 1)  # a few levels, still small enough to keep the bounds
+        o = rng.uniform(-0.9, 0.9, (20000, 3)).astype(np.float32)
+        o[:, 2] += 1.0
+        d = rng.normal(size=(20000, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        both(o, d)
+        V, I, centre, qrng, n_quads = geom_cases.quad_scene()
+        hostcheck.hc_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
+        both(*geom_cases.quad_rays(V, I, qrng), want_exact=bool(hostcheck.hc_has_exact_bounds()))
+    finally:
+        hostcheck.hc_set_wide_nodes(0)
+        hostcheck.hc_scene_cornell()
+
+
 def test_watertight_no_leak_through_shared_edges(hostcheck):
     """Rays aimed exactly at quad diagonals, edges and corners of the closed part of the box
     must hit something (the two triangles of a quad share their diagonal)."""

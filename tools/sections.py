@@ -19,6 +19,10 @@ n = L.pt_dbg_profile_counters(buf)
 rr, rs = gpu.ray_counts()
 print("sections", n, "rays", rr, rs, "ms", L.pt_last_render_ms())
 bounce_waves = buf[0]
-for k in range(n):
+TNAMES = ["loop", "regen", "trace", "shade", "enqueue", "shadow", "epilogue", "node", "tri"]
+for k in range(18):
     waves, lanes = buf[2 * k], buf[2 * k + 1]
     print(f"{NAMES[k]:10s} waves {waves:14d}  per-bounce-wave {waves / max(bounce_waves, 1):7.3f}  lanes/wave {lanes / max(waves, 1):6.2f}")
+tot = buf[40] + buf[46]
+for k, name in enumerate(TNAMES):
+    print(f"time {name:10s} {buf[40 + k]:16d} ticks  {buf[40 + k] / max(tot, 1):6.1%} of loop + epilogue")
