@@ -1,6 +1,7 @@
 // bvh_build.cpp -- binned-SAH binary build, greedy collapse to 8-wide nodes, octant-ordered
 // slot assignment and 8-bit box quantisation.
 #include "bvh_build.h"
+#include "pt_bvh.h"
 
 #include <algorithm>
 #include <atomic>
@@ -463,6 +464,10 @@ struct Emitter {
   // A ray that leaves a surface cannot hit a triangle lying in that surface's plane; traversal drops
   // such candidates up front.  Planes are compared through the unit normal and offset of each triangle.
   void mark_coplanar(uint32_t node_index, uint32_t first, uint32_t count) {
+    mark_coplanar(node_index, first, count, out.home_node.data(), 1, out.home_mask.data(), 1);
+  }
+  // writes node_index to hn[prim * hn_stride] and the mask to hm[prim * hm_stride]
+  void mark_coplanar(uint32_t node_index, uint32_t first, uint32_t count, uint32_t* hn, int hn_stride, uint32_t* hm, int hm_stride) {
     double pl[24][4];
     uint32_t prim[24];
     bool ok[24];
@@ -493,14 +498,99 @@ struct Emitter {
           if (same) mask |= 1u << j;
         }
       }
-      out.home_node[prim[i]] = node_index;
-      out.home_mask[prim[i]] = mask;
+      hn[(size_t)prim[i] * hn_stride] = node_index;
+      hm[(size_t)prim[i] * hm_stride] = mask;
       if (f2u(out.tris[4 * (size_t)(first + i) + 2].w)) {  // the partner lies in the same plane
         const uint32_t partner = f2u(out.tris[4 * (size_t)(first + i) + 3].w);
-        out.home_node[partner] = node_index;
-        out.home_mask[partner] = mask;
+        hn[(size_t)partner * hn_stride] = node_index;
+        hm[(size_t)partner * hm_stride] = mask;
       }
     }
+  }
+
+  // ---- wide nodes for small trees (layout: pt_bvh.h)
+  std::vector<float> slot_boxes;  // per node and slot: the child's box, lo xyz hi xyz (filled by emit)
+  struct WideLeaf {
+    const float* box;
+    uint32_t first, count;  // items, relative to the packed tree's item order
+  };
+  // leaf slots of the subtree below packed node i, in item order
+  void collect_leaves(uint32_t i, std::vector<WideLeaf>& leaves) const {
+    const BvhNode& nd = out.nodes[i];
+    uint32_t rank = 0;
+    std::vector<uint32_t> kids;
+    for (int s = 0; s < 8; ++s) {
+      const uint32_t meta = nd.meta[s];
+      if (!meta) continue;
+      if (((meta & (meta << 1)) & 0x10u) != 0u) {
+        kids.push_back(nd.child_base + rank++);
+      } else {
+        const uint32_t unary = (meta >> 5) & 7u;
+        leaves.push_back(WideLeaf{&slot_boxes[48 * (size_t)i + 6 * s], nd.tri_base + (meta & 0x1fu),
+                                  (uint32_t)__builtin_popcount(unary)});
+      }
+    }
+    for (uint32_t k : kids) collect_leaves(k, leaves);
+  }
+  static float round_down(double v) {
+    float f = (float)v;
+    return (double)f > v ? std::nextafterf(f, -INFINITY) : f;
+  }
+  static float round_up(double v) {
+    float f = (float)v;
+    return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+  }
+  void put_slot(u4* node, int slot, const float* box, uint32_t bits) const {
+    uint32_t* w = reinterpret_cast<uint32_t*>(node);
+    w[4 * kWideBits + slot] = bits;
+    // padded by a few 1e-6 of the scene's size: covers the rounding of t = plane * (1/d) - o * (1/d)
+    const double pad = 4e-6 * std::max((double)out.vmag, 1e-3);
+    for (int k = 0; k < 3; ++k) {
+      w[4 * (kWideBounds + kWidePlane * k) + slot] = f2u(box ? round_down((double)box[k] - pad) : 3e38f);
+      w[4 * (kWideBounds + kWidePlane * (3 + k)) + slot] = f2u(box ? round_up((double)box[3 + k] + pad) : -3e38f);
+    }
+  }
+  int wide_node(uint32_t i) {
+    u4* node = out.wide_nodes.data() + (size_t)kWideNodeWords * i;
+    for (int slot = 0; slot < 16; ++slot) put_slot(node, slot, nullptr, 0u);
+    const BvhNode& nd = out.nodes[i];
+    std::vector<WideLeaf> leaves;
+    collect_leaves(i, leaves);
+    uint32_t items = 0;
+    for (const WideLeaf& l : leaves) items = std::max(items, l.first + l.count - nd.tri_base);
+    if (leaves.size() <= 16 && items <= 24) {  // the whole subtree in one node
+      for (size_t k = 0; k < leaves.size(); ++k)
+        put_slot(node, (int)k, leaves[k].box, ((1u << leaves[k].count) - 1u) << (leaves[k].first - nd.tri_base));
+      node[0] = u4{nd.tri_base << 8, 0u, (uint32_t)std::max<size_t>((leaves.size() + 3) / 4, 1), 0u};
+      out.wide_groups = std::max(out.wide_groups, node[0].z);
+      mark_coplanar(i, nd.tri_base, items, out.home_wide.data(), 2, out.home_wide.data() + 1, 2);
+      return 1;
+    }
+    int below = 0;
+    uint32_t rank = 0, own_items = 0;
+    for (int s = 0; s < 8; ++s) {
+      const uint32_t meta = nd.meta[s];
+      if (!meta) continue;
+      const float* box = &slot_boxes[48 * (size_t)i + 6 * s];
+      if (((meta & (meta << 1)) & 0x10u) != 0u) {
+        put_slot(node, s, box, 1u << (24 + s));
+        below = std::max(below, wide_node(nd.child_base + rank++));
+      } else {
+        const uint32_t unary = (meta >> 5) & 7u;
+        put_slot(node, s, box, unary << (meta & 0x1fu));
+        own_items = std::max(own_items, (meta & 0x1fu) + (uint32_t)__builtin_popcount(unary));
+      }
+    }
+    node[0] = u4{(uint32_t)nd.imask | (nd.tri_base << 8), nd.child_base, 2u, 0u};
+    out.wide_groups = std::max(out.wide_groups, 2u);
+    mark_coplanar(i, nd.tri_base, own_items, out.home_wide.data(), 2, out.home_wide.data() + 1, 2);
+    return 1 + below;
+  }
+  void build_wide() {
+    out.wide_nodes.assign((size_t)kWideNodeWords * out.nodes.size(), u4{0u, 0u, 0u, 0u});
+    out.home_wide.assign(2 * (size_t)out.num_tris, 0u);
+    out.wide_groups = 1;
+    out.wide_depth = wide_node(0);
   }
 
   // returns the number of internal-node levels below and including this node
@@ -575,11 +665,6 @@ struct Emitter {
       if (c < 0) {
         node.meta[s] = 0;
         for (int k = 0; k < 3; ++k) { qlo[k][s] = 255; qhi[k][s] = 0; }
-        if (!out.exact_bounds.empty())
-          for (int k = 0; k < 3; ++k) {
-            out.exact_bounds[48 * (size_t)out_index + 8 * k + s] = 255.0f;
-            out.exact_bounds[48 * (size_t)out_index + 24 + 8 * k + s] = 0.0f;
-          }
         continue;
       }
       const Node2& cn = b.nodes2[c];
@@ -590,15 +675,9 @@ struct Emitter {
         double hi = std::ceil(ghi);
         qlo[k][s] = (uint8_t)std::min(std::max(lo, 0.0), 255.0);
         qhi[k][s] = (uint8_t)std::min(std::max(hi, 0.0), 255.0);
-        if (!out.exact_bounds.empty()) {
-          // the same box, unquantised: widened by a few 1e-6 of the scene's size and rounded outwards
-          const double padg = 4e-6 * std::max((double)out.vmag, 1e-3) / sc;
-          float flo = (float)(glo - padg), fhi = (float)(ghi + padg);
-          if ((double)flo > glo - padg) flo = std::nextafterf(flo, -INFINITY);
-          if ((double)fhi < ghi + padg) fhi = std::nextafterf(fhi, INFINITY);
-          float* ex = out.exact_bounds.data() + 48 * (size_t)out_index;
-          ex[8 * k + s] = std::max(flo, (float)qlo[k][s]);        // never looser than the quantised box
-          ex[24 + 8 * k + s] = std::min(fhi, (float)qhi[k][s]);
+        if (!slot_boxes.empty()) {  // small tree: remember the child's box itself for the wide nodes
+          slot_boxes[48 * (size_t)out_index + 6 * s + k] = cn.box.lo[k];
+          slot_boxes[48 * (size_t)out_index + 6 * s + 3 + k] = cn.box.hi[k];
         }
       }
       if (cn.count == 0) {
@@ -728,8 +807,9 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   em.below.assign(b.nodes2.size(), 0u);
   const uint32_t nodes_below_root = em.count_below(root2);
   out.nodes.resize(1 + (size_t)nodes_below_root);
-  if (out.nodes.size() <= kExactBoundsMaxNodes) out.exact_bounds.assign(48 * out.nodes.size(), 0.0f);
+  if (out.nodes.size() <= kWideMaxNodes) em.slot_boxes.assign(48 * out.nodes.size(), 0.0f);
   out.depth = em.emit(0, root2, 1u, 0u);
+  if (!em.slot_boxes.empty()) em.build_wide();
   if (timing)
     fprintf(stderr, "bvh build: %d triangles in %d leaf items, binary tree %.2f s (%d threads), collapse %.2f s, emit %.2f s\n", num_tris, num_items,
             secs(t0, t1), b.max_threads, secs(t1, t2), secs(t2, now()));

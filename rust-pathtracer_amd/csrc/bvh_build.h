@@ -21,17 +21,19 @@ struct BvhBuildResult {
   // (bits 0-1: the input corner that comes first, ...); 0x24 = as given.  Barycentrics of a hit refer to
   // this order.
   std::vector<uint8_t> corner_order;
-  // Small trees only (at most kExactBoundsMaxNodes nodes, else empty): per node 48 floats, the child boxes in
-  // the node's grid units but NOT rounded to the 8-bit grid -- lo x, lo y, lo z, hi x, hi y, hi z, 8 slots each,
-  // padded outwards by a few ulps; an empty slot is (255, 0).  Kernels that unpack the nodes into LDS test these
-  // instead of the quantised boxes: same hits, fewer false candidates.
-  std::vector<float> exact_bounds;
+  // Small trees only (at most kWideMaxNodes nodes, else empty): the tree as wide nodes for kernels that keep
+  // it in LDS (layout: pt_bvh.h), kWideNodeWords u4 per node under the packed tree's node indices, and where
+  // each primitive lives in that tree ({node, item bits} per primitive, as home_node / home_mask).
+  std::vector<u4> wide_nodes;
+  std::vector<uint32_t> home_wide;
+  int wide_depth = 0;          // levels of internal nodes of the wide tree
+  uint32_t wide_groups = 2;    // the most slot groups (of four slots) any wide node uses
   int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
   int num_tris = 0;
   int num_items = 0;           // leaf items: single triangles, or two triangles forming a parallelogram
 };
 
-constexpr size_t kExactBoundsMaxNodes = 96;
+constexpr size_t kWideMaxNodes = 96;
 
 // Whether consecutive triangles that form a parallelogram share one leaf item (default: yes, unless the
 // environment says PT_BVH_PAIRS=0); on < 0 returns to that default.  Applies to the next build.

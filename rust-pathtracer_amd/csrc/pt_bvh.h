@@ -249,66 +249,59 @@ PT_HD uint32_t intersect_children(const NodeWords& n, const RayBox& rb, float tm
   return mask;
 }
 
-// Nodes of a scene small enough to live in LDS are kept there unpacked, 256 bytes each (16 x u4), so that a
-// visit does not spend half its instructions on decoding what is the same for every lane:
-//   u4[0] = grid origin x y z (float bits), imask | first leaf item << 8
-//   u4[1] = grid step x y z (float bits: 2^e), first internal child
-//   u4[2..3]  = per slot, the traversal bits the child contributes when its box is hit (leaf: its item bits;
-//               internal: bit 24 + slot, moved to 24 + (slot ^ octinv) after the test)
-//   u4[4..15] = the quantised bounds as floats, 8 slots each: lo x, lo y, lo z, hi x, hi y, hi z
-// The box arithmetic is that of intersect_children, operation for operation, so both forms agree bit for bit.
-constexpr uint32_t kWideNodeWords = 16;
+// Wide nodes: the form in which a small tree is kept in LDS by the fused kernels (built on the host,
+// bvh_build.cpp: build_wide).  A node is kWideNodeWords u4 and holds up to 16 slots in groups of four:
+//   u4[0]      = imask | first leaf item << 8, first internal child, number of slot groups in use (1..4), 0
+//                (kernels run SceneView::wide_groups groups on every node: unused slots are never hit)
+//   u4[1..4]   = per slot, the traversal bits the child contributes when its box is hit (leaf: its item bits;
+//                internal: bit 24 + slot, moved to 24 + (slot ^ octinv) after the test)
+//   u4[5..28]  = the child boxes in world coordinates as floats, 16 slots each: lo x, lo y, lo z, hi x, hi y, hi z
+//                (unquantised, padded outwards; an empty slot is (+big, -big))
+// Node indices are those of the packed tree.  A subtree with at most 16 leaf slots and 24 items is flattened
+// into its root (no internal children; its descendants' entries are unused), otherwise a node keeps its 8
+// slots.  Boxes are never tighter than the children, so hits are those of the packed tree; only the
+// candidates tested for nothing differ.
+constexpr uint32_t kWideNodeWords = 32;
+constexpr uint32_t kWideBits = 1, kWideBounds = 5, kWidePlane = 4;  // u4 offsets / u4 per plane
 
-PT_HD void unpack_node_slot(const BvhNode& nd, int j, uint32_t* w) {
-  w[16 + j] = f2u((float)nd.qlox[j]); w[24 + j] = f2u((float)nd.qloy[j]); w[32 + j] = f2u((float)nd.qloz[j]);
-  w[40 + j] = f2u((float)nd.qhix[j]); w[48 + j] = f2u((float)nd.qhiy[j]); w[56 + j] = f2u((float)nd.qhiz[j]);
-  const uint32_t meta = nd.meta[j];
-  const bool inner = ((meta & (meta << 1)) & 0x10u) != 0u;
-  w[8 + j] = inner ? 1u << (meta & 0x1fu) : ((meta >> 5) & 7u) << (meta & 0x1fu);
-  if (j == 0) {
-    w[0] = f2u(nd.px); w[1] = f2u(nd.py); w[2] = f2u(nd.pz);
-    w[3] = (uint32_t)nd.imask | (nd.tri_base << 8);
-    w[4] = (uint32_t)nd.ex << 23; w[5] = (uint32_t)nd.ey << 23; w[6] = (uint32_t)nd.ez << 23;
-    w[7] = nd.child_base;
-  }
-}
+// Ray constants of the wide test: t = plane * idir + oi with oi = -o * idir.
+struct RayWide {
+  f3 idir, oi;
+  uint32_t octinv;
+};
 
-// Replace slot j's bounds in an unpacked node by the unquantised ones the builder kept for small trees
-// (BvhBuildResult::exact_bounds: 48 floats per node in the same order as words 16..63).  Boxes only get
-// tighter (never tighter than the child), so the hits are the same and fewer items are tested for nothing.
-PT_HD void unpack_exact_bounds(const float* ex, int j, uint32_t* w) {
-  for (int a = 0; a < 6; ++a) w[16 + 8 * a + j] = f2u(ex[8 * a + j]);
-}
-
-PT_HD uint32_t intersect_children_wide(const u4* n, const RayBox& rb, float tmin, float tmax) {
-  const u4 ha = n[0], hb = n[1];
-  const float sx = u2f(hb.x) * rb.idir.x, sy = u2f(hb.y) * rb.idir.y, sz = u2f(hb.z) * rb.idir.z;
-  const float bx = (u2f(ha.x) - rb.o.x) * rb.idir.x;
-  const float by = (u2f(ha.y) - rb.o.y) * rb.idir.y;
-  const float bz = (u2f(ha.z) - rb.o.z) * rb.idir.z;
-  const bool px = (rb.octinv & 4u) != 0u, py = (rb.octinv & 2u) != 0u, pz = (rb.octinv & 1u) != 0u;
-  const u4* nx = n + (px ? 4 : 10), *fx = n + (px ? 10 : 4);
-  const u4* ny = n + (py ? 6 : 12), *fy = n + (py ? 12 : 6);
-  const u4* nz = n + (pz ? 8 : 14), *fz = n + (pz ? 14 : 8);
+PT_HD uint32_t intersect_children_wide(const u4* n, const RayWide& rw, float tmin, float tmax, uint32_t groups) {
+  const bool px = (rw.octinv & 4u) != 0u, py = (rw.octinv & 2u) != 0u, pz = (rw.octinv & 1u) != 0u;
+  const u4* b = n + kWideBounds;
+  const u4* nx = b + (px ? 0 : 3) * kWidePlane, *fx = b + (px ? 3 : 0) * kWidePlane;
+  const u4* ny = b + (py ? 1 : 4) * kWidePlane, *fy = b + (py ? 4 : 1) * kWidePlane;
+  const u4* nz = b + (pz ? 2 : 5) * kWidePlane, *fz = b + (pz ? 5 : 2) * kWidePlane;
   uint32_t mask = 0;
+  // one group of four slots per trip; the counter is hidden from the optimiser (an empty asm), which otherwise
+  // unrolls or software-pipelines the loop and spills dozens of registers doing so
+  uint32_t g = 0;
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    const u4 w = n[2 + half];
-    const u4 ax = nx[half], bxw = fx[half], ay = ny[half], byw = fy[half], az = nz[half], bzw = fz[half];
+  do {
+    const u4 w = n[kWideBits + g];
+    const u4 ax = nx[g], bxw = fx[g], ay = ny[g], byw = fy[g], az = nz[g], bzw = fz[g];
     const uint32_t wj[4] = {w.x, w.y, w.z, w.w};
     const uint32_t nxj[4] = {ax.x, ax.y, ax.z, ax.w}, fxj[4] = {bxw.x, bxw.y, bxw.z, bxw.w};
     const uint32_t nyj[4] = {ay.x, ay.y, ay.z, ay.w}, fyj[4] = {byw.x, byw.y, byw.z, byw.w};
     const uint32_t nzj[4] = {az.x, az.y, az.z, az.w}, fzj[4] = {bzw.x, bzw.y, bzw.z, bzw.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float tnx = u2f(nxj[j]) * sx + bx, tfx = u2f(fxj[j]) * sx + bx;
-      const float tny = u2f(nyj[j]) * sy + by, tfy = u2f(fyj[j]) * sy + by;
-      const float tnz = u2f(nzj[j]) * sz + bz, tfz = u2f(fzj[j]) * sz + bz;
+      const float tnx = u2f(nxj[j]) * rw.idir.x + rw.oi.x, tfx = u2f(fxj[j]) * rw.idir.x + rw.oi.x;
+      const float tny = u2f(nyj[j]) * rw.idir.y + rw.oi.y, tfy = u2f(fyj[j]) * rw.idir.y + rw.oi.y;
+      const float tnz = u2f(nzj[j]) * rw.idir.z + rw.oi.z, tfz = u2f(fzj[j]) * rw.idir.z + rw.oi.z;
       const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
       const float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
       if (tn <= tf) mask |= wj[j];
     }
-  }
+    ++g;
+#if PT_ON_DEVICE
+    asm volatile("" : "+s"(g));
+#endif
+  } while (g < groups);
   if (mask & 0xff000000u) {  // internal children: slot s is visited in the order of s ^ octinv
     uint32_t top = mask >> 24;
     if (px) top = ((top & 0xf0u) >> 4) | ((top & 0x0fu) << 4);
@@ -336,14 +329,20 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
   Hit hit{-1, tmax, 0.f, 0.f};
   uint32_t home_node = 0xffffffffu, home_mask = 0u;
   if (origin) {
-    const ShadeRec* rec = sc.shade + (origin - 1u);
-    home_node = rec->home_node;
-    home_mask = rec->home_mask;
+    if (sc.wide) {  // the wide tree has its own node numbering of where a primitive lives
+      home_node = sc.home_wide[2u * (origin - 1u)];
+      home_mask = sc.home_wide[2u * (origin - 1u) + 1u];
+    } else {
+      const ShadeRec* rec = sc.shade + (origin - 1u);
+      home_node = rec->home_node;
+      home_mask = rec->home_mask;
+    }
   }
   RayBox rb;
   rb.o = o;
   rb.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   rb.octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+
   const float rmag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.vmag;
 
   StackEntry cur{0u, 0x80000000u};
@@ -363,11 +362,21 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
       uint32_t hm;
       if (sc.wide) {
         const u4* n = sc.wide + kWideNodeWords * node_index;
-        hm = intersect_children_wide(n, rb, tmin, hit.t);
-        const uint32_t packed = n[0].w;
-        cur.base = n[1].w;
-        cur.bits = (hm & 0xff000000u) | (packed & 0xffu);
-        tg.base = packed >> 8;
+        const u4 head = n[0];
+        // -o / d is recomputed at every visit (three multiplies) rather than kept in registers across the
+        // traversal; the empty asm keeps the compiler from hoisting it out of the loop again
+        f3 oo = o;
+#if PT_ON_DEVICE
+        asm volatile("" : "+v"(oo.x), "+v"(oo.y), "+v"(oo.z));
+#endif
+        RayWide rw;
+        rw.idir = rb.idir;
+        rw.oi = mk3(-oo.x * rb.idir.x, -oo.y * rb.idir.y, -oo.z * rb.idir.z);
+        rw.octinv = rb.octinv;
+        hm = intersect_children_wide(n, rw, tmin, hit.t, sc.wide_groups);  // the same trip count on every lane
+        cur.base = head.y;
+        cur.bits = (hm & 0xff000000u) | (head.x & 0xffu);
+        tg.base = head.x >> 8;
       } else {
         const NodeWords n = load_node(sc.nodes, node_index);
         hm = intersect_children(n, rb, tmin, hit.t);

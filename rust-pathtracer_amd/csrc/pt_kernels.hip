@@ -388,27 +388,28 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
 #ifndef PT_BOUNCE_WAVES
 #define PT_BOUNCE_WAVES 4
 #endif
-// Small scenes: nodes (unpacked, pt_bvh.h), item records and shading records are staged in LDS behind the
-// traversal stacks, so the divergent 16-byte gathers of traversal and shading never leave the CU.  Returns
-// the first free u4 after the staged scene.
+// Small scenes: wide nodes (pt_bvh.h), item records, shading records and the wide tree's home table are staged
+// in LDS behind the traversal stacks, so the divergent 16-byte gathers of traversal and shading never leave
+// the CU.  Returns the first free u4 after the staged scene.
+__host__ __device__ inline uint32_t staged_scene_words(uint32_t nodes, uint32_t items, uint32_t tris) {
+  return nodes * kWideNodeWords + items * (uint32_t)kTriWords + tris * 6u + (2u * tris + 3u) / 4u;
+}
 __device__ __forceinline__ u4* stage_scene(const RenderParams& p, u4* dst, SceneView& sc) {
   const uint32_t n_nodes16 = p.scene_nodes * kWideNodeWords, n_tris16 = p.scene.num_items * (uint32_t)kTriWords,
-                 n_shade16 = p.scene.num_tris * 6u;
+                 n_shade16 = p.scene.num_tris * 6u, n_home = 2u * p.scene.num_tris;
   const u4* src_t = reinterpret_cast<const u4*>(p.scene.tris);
   const u4* src_s = reinterpret_cast<const u4*>(p.scene.shade);
-  for (uint32_t k = threadIdx.x; k < p.scene_nodes * 8u; k += blockDim.x) {
-    uint32_t* w = reinterpret_cast<uint32_t*>(dst + kWideNodeWords * (k >> 3));
-    const uint32_t j = k & 7u;
-    unpack_node_slot(p.scene.nodes[k >> 3], (int)j, w);
-    if (p.scene.exact) unpack_exact_bounds(p.scene.exact + 48u * (k >> 3), (int)j, w);  // small trees: unquantised boxes
-  }
+  for (uint32_t k = threadIdx.x; k < n_nodes16; k += blockDim.x) dst[k] = p.scene.wide_src[k];
   for (uint32_t k = threadIdx.x; k < n_tris16; k += blockDim.x) dst[n_nodes16 + k] = src_t[k];
   for (uint32_t k = threadIdx.x; k < n_shade16; k += blockDim.x) dst[n_nodes16 + n_tris16 + k] = src_s[k];
+  uint32_t* home = reinterpret_cast<uint32_t*>(dst + n_nodes16 + n_tris16 + n_shade16);
+  for (uint32_t k = threadIdx.x; k < n_home; k += blockDim.x) home[k] = p.scene.home_wide[k];
   __syncthreads();
   sc.wide = dst;
   sc.tris = reinterpret_cast<const q4*>(dst + n_nodes16);
   sc.shade = reinterpret_cast<const ShadeRec*>(dst + n_nodes16 + n_tris16);
-  return dst + n_nodes16 + n_tris16 + n_shade16;
+  sc.home_wide = home;
+  return dst + staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
 }
 
 template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
@@ -860,8 +861,8 @@ void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
-  const size_t scene_bytes = (size_t)p.scene_nodes * (16u * kWideNodeWords) + (size_t)p.scene.num_items * (16u * kTriWords) + (size_t)p.scene.num_tris * 96u;
-  const bool lds_scene = p.scene_in_lds && scene_bytes <= 24u * 1024u;
+  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
+  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= 24u * 1024u;
   size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
   const bool guided = p.guiding || p.train;
   if (p.defer_shadow && !p.acc2) {

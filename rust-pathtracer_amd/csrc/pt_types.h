@@ -231,8 +231,14 @@ struct GuideView {
 
 struct SceneView {
   const BvhNode* nodes;
-  const u4* wide;            // the same nodes unpacked (pt_bvh.h), or null: set by kernels that stage the scene in LDS
-  const float* exact;        // small trees: 48 unquantised child bounds per node in grid units (bvh_build.h), or null
+  // Small trees also exist as wide nodes (pt_bvh.h): wide_src in device memory (null for large trees), and
+  // home_wide = per primitive {node, item bits} of where it lives in the wide tree.  Kernels that stage the
+  // scene in LDS point `wide` (and home_wide) at their copy; everywhere else `wide` is null and traversal
+  // reads the packed nodes.
+  const u4* wide;
+  const u4* wide_src;
+  const uint32_t* home_wide;
+  uint32_t wide_groups;      // slot groups to test per wide node: the most any node of the tree uses
   // 4 x q4 per leaf item (a triangle, or two forming a parallelogram) in BVH leaf order (see the record
   // layout in pt_bvh.h): v0 and the rows that map (p - v0) to the barycentrics of v1, v2 and to the distance
   // from the plane

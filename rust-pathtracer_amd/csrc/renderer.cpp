@@ -193,8 +193,12 @@ void upload_scene(State& s) {
   upload(s.d_nodes, bvh.nodes);
   upload(s.d_tris, bvh.tris);
   upload(s.d_shade, recs);
-  upload(s.d_exact, bvh.exact_bounds);
-  s.scene.exact = bvh.exact_bounds.empty() ? nullptr : s.d_exact;
+  upload(s.d_wide, bvh.wide_nodes);
+  upload(s.d_home_wide, bvh.home_wide);
+  s.scene.wide = nullptr;
+  s.scene.wide_src = bvh.wide_nodes.empty() ? nullptr : s.d_wide;
+  s.scene.home_wide = bvh.wide_nodes.empty() ? nullptr : s.d_home_wide;
+  s.scene.wide_groups = bvh.wide_groups;
   s.scene.nodes = s.d_nodes;
   s.scene.tris = s.d_tris;
   s.scene.shade = s.d_shade;
@@ -750,7 +754,7 @@ State::~State() {
   if (stream) (void)hipStreamSynchronize(stream);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   for (TimedLaunch& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
-  dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade); dev_free(d_exact);
+  dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade); dev_free(d_wide); dev_free(d_home_wide);
   dev_free(st_o); dev_free(st_d); dev_free(st_s); dev_free(st_m); dev_free(acc); dev_free(hits);
   dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started);
   dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
@@ -933,7 +937,8 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
   const size_t nodes_b = (bvh.nodes.size() * sizeof(BvhNode) + 255u) & ~(size_t)255u;
   const size_t tris_b = (bvh.tris.size() * sizeof(q4) + 255u) & ~(size_t)255u;
   const size_t shade_b = ((size_t)std::max(scene().num_tris(), 1) * sizeof(ShadeRec) + 255u) & ~(size_t)255u;
-  const size_t exact_b = bvh.exact_bounds.size() * sizeof(float);
+  const size_t wide_b = (bvh.wide_nodes.size() * sizeof(u4) + 255u) & ~(size_t)255u;
+  const size_t exact_b = wide_b + bvh.home_wide.size() * sizeof(uint32_t);
   if (nodes_b + tris_b + shade_b + exact_b > kNaMaxSceneBytes) {
     fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: the scene (%zu bytes of nodes, items and shading records) "
                     "exceeds the %zu bytes reserved for it\n", nodes_b + tris_b + shade_b + exact_b, kNaMaxSceneBytes);
@@ -947,9 +952,16 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
     HIP_CHECK(hipMemcpy(dn, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(dt, bvh.tris.data(), bvh.tris.size() * sizeof(q4), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(ds, recs.data(), recs.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
-    float* dx = reinterpret_cast<float*>(na.scene_mem + nodes_b + tris_b + shade_b);
-    if (exact_b) HIP_CHECK(hipMemcpy(dx, bvh.exact_bounds.data(), exact_b, hipMemcpyHostToDevice));
-    s.scene.exact = exact_b ? dx : nullptr;
+    u4* dw = reinterpret_cast<u4*>(na.scene_mem + nodes_b + tris_b + shade_b);
+    uint32_t* dh = reinterpret_cast<uint32_t*>(na.scene_mem + nodes_b + tris_b + shade_b + wide_b);
+    if (!bvh.wide_nodes.empty()) {
+      HIP_CHECK(hipMemcpy(dw, bvh.wide_nodes.data(), bvh.wide_nodes.size() * sizeof(u4), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(dh, bvh.home_wide.data(), bvh.home_wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    s.scene.wide = nullptr;
+    s.scene.wide_src = bvh.wide_nodes.empty() ? nullptr : dw;
+    s.scene.home_wide = bvh.wide_nodes.empty() ? nullptr : dh;
+    s.scene.wide_groups = bvh.wide_groups;
     s.scene.nodes = dn;
     s.scene.tris = dt;
     s.scene.shade = ds;

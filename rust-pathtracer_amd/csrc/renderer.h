@@ -48,7 +48,8 @@ struct State {
   BvhNode* d_nodes = nullptr;
   q4* d_tris = nullptr;
   ShadeRec* d_shade = nullptr;
-  float* d_exact = nullptr;  // unquantised child bounds of a small tree (BvhBuildResult::exact_bounds)
+  u4* d_wide = nullptr;            // small trees: wide nodes and the primitives' places in them (bvh_build.h)
+  uint32_t* d_home_wide = nullptr;
   SceneView scene{};
   int bvh_depth = 1, num_nodes = 0;
   size_t bvh_bytes = 0;

@@ -102,23 +102,18 @@ void hc_scene_get(float* v, uint32_t* idx, float* nrm, float* m11) {
 }
 void hc_set_origin_skip(int on) { g_origin_skip = on; }
 // traverse the unpacked form of the nodes (what the fused kernels keep in LDS) instead of the packed one
-std::vector<u4> g_wide;
 void hc_set_wide_nodes(int on) {
   ensure();
-  g_wide.assign(on ? g_bvh.nodes.size() * kWideNodeWords : 0, u4{0u, 0u, 0u, 0u});
-  if (on)
-    for (size_t k = 0; k < g_bvh.nodes.size() * 8; ++k) {
-      uint32_t* w = reinterpret_cast<uint32_t*>(g_wide.data() + kWideNodeWords * (k >> 3));
-      unpack_node_slot(g_bvh.nodes[k >> 3], (int)(k & 7), w);
-      // on == 2: with the unquantised bounds, as the kernels do when the builder kept them
-      if (on == 2 && !g_bvh.exact_bounds.empty()) unpack_exact_bounds(g_bvh.exact_bounds.data() + 48 * (k >> 3), (int)(k & 7), w);
-    }
-  g_sv.wide = on ? g_wide.data() : nullptr;
+  const bool use = on && !g_bvh.wide_nodes.empty();
+  g_sv.wide = use ? g_bvh.wide_nodes.data() : nullptr;
+  g_sv.home_wide = use ? g_bvh.home_wide.data() : nullptr;
+  g_sv.wide_groups = g_bvh.wide_groups;
 }
+int hc_has_wide_nodes() { ensure(); return g_bvh.wide_nodes.empty() ? 0 : 1; }
+int hc_wide_depth() { ensure(); return g_bvh.wide_depth; }
 // rebuilds the current scene's tree with or without parallelogram items
 void hc_set_pairing(int on) { bvh_set_pairing(on); ensure(); finish_scene(); }
 int hc_num_items() { ensure(); return g_bvh.num_items; }
-int hc_has_exact_bounds() { ensure(); return g_bvh.exact_bounds.empty() ? 0 : 1; }
 // FNV-1a over the built BVH arrays (nodes, triangle records, home masks)
 unsigned long long hc_bvh_hash() {
   ensure();

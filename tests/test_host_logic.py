@@ -202,53 +202,20 @@ def test_parallelogram_items_give_the_triangles_answers(hostcheck):
     assert hostcheck.hc_num_items() == 12  # the built-in scene is twelve quads
 
 
-def test_unpacked_nodes_traverse_like_packed_ones(hostcheck):
-    """The fused kernels keep small scenes' nodes unpacked in LDS (bounds as floats, traversal bits per
-    slot precomputed).  Same arithmetic, so the same hits bit for bit: built-in scene, a deeper tree and the
-    quad scene, closest-hit and any-hit."""
-    import geom_cases
-    rng = np.random.default_rng(5)
-
-    def both(o, d):
-        out = []
-        tmax = rng.uniform(0.2, 4.0, len(o)).astype(np.float32)
-        for wide in (0, 1):
-            hostcheck.hc_set_wide_nodes(wide)
-            out.append(_hc_trace(hostcheck, o, d) + (_hc_trace(hostcheck, o, d, tmax, any_hit=1)[0],))
-        hostcheck.hc_set_wide_nodes(0)
-        for a, b in zip(*out):
-            assert np.array_equal(a, b)
-        assert (out[0][0] >= 0).mean() > 0.3
-
-    try:
-        hostcheck.hc_scene_cornell()
-        both(*_random_rays(20000, 5))
-        hostcheck.hc_scene_synthetic(7, 64, 2)  # several levels: internal children, every octant order
-        o = rng.uniform(-0.9, 0.9, (20000, 3)).astype(np.float32)
-        o[:, 2] += 1.0
-        d = rng.normal(size=(20000, 3)).astype(np.float32)
-        d /= np.linalg.norm(d, axis=1, keepdims=True)
-        both(o, d)
-        V, I, centre, qrng, n_quads = geom_cases.quad_scene()
-        hostcheck.hc_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
-        both(*geom_cases.quad_rays(V, I, qrng))
-    finally:
-        hostcheck.hc_set_wide_nodes(0)
-        hostcheck.hc_scene_cornell()
-
-
-def test_unquantised_bounds_give_the_same_hits(hostcheck):
-    """Small trees keep their child boxes unquantised for the kernels that unpack nodes into LDS: tighter boxes,
-    so fewer candidates, but every hit (primitive, distance, barycentrics, occlusion) is the packed tree's,
-    bit for bit -- including rays aimed at edges and corners of the closed box."""
+def test_wide_nodes_give_the_packed_trees_hits(hostcheck):
+    """Small trees also exist as wide nodes for the kernels that keep the scene in LDS: unquantised boxes in
+    world coordinates, up to 16 slots, subtrees of at most 16 leaves flattened into one node (the built-in
+    scene: one node).  Fewer candidates and node visits, but every hit (primitive, distance, barycentrics,
+    occlusion) is the packed tree's, bit for bit -- including rays aimed at edges and corners of the closed box
+    -- and so is a whole render with the origin-plane skip, which uses the wide tree's own home table."""
     import geom_cases
     rng = np.random.default_rng(11)
 
     def both(o, d, want_exact=True):
-        assert hostcheck.hc_has_exact_bounds() == (1 if want_exact else 0)
+        assert hostcheck.hc_has_wide_nodes() == (1 if want_exact else 0)
         out = []
         tmax = rng.uniform(0.2, 4.0, len(o)).astype(np.float32)
-        for mode in (0, 2):
+        for mode in (0, 1):
             hostcheck.hc_set_wide_nodes(mode)
             out.append(_hc_trace(hostcheck, o, d) + (_hc_trace(hostcheck, o, d, tmax, any_hit=1)[0],))
         hostcheck.hc_set_wide_nodes(0)
@@ -257,6 +224,7 @@ def test_unquantised_bounds_give_the_same_hits(hostcheck):
 
     try:
         hostcheck.hc_scene_cornell()
+        assert hostcheck.hc_wide_depth() == 1  # twelve quads: one flat node
         both(*_random_rays(40000, 6))
         # rays from inside the room at points on edges, corners and quad diagonals
         targets = []
@@ -278,8 +246,22 @@ def test_unquantised_bounds_give_the_same_hits(hostcheck):
         both(o, d)
         V, I, centre, qrng, n_quads = geom_cases.quad_scene()
         hostcheck.hc_scene_triangles(P(V), len(V), P(I, C.c_uint32), len(I), None)
-        both(*geom_cases.quad_rays(V, I, qrng), want_exact=bool(hostcheck.hc_has_exact_bounds()))
+        both(*geom_cases.quad_rays(V, I, qrng), want_exact=bool(hostcheck.hc_has_wide_nodes()))
+        # whole renders: packed tree, wide tree, wide tree without the origin-plane skip -- the same bits
+        hostcheck.hc_scene_cornell()
+        w, h = 40, 30
+        outs = []
+        for wide, skip in ((0, 1), (1, 1), (1, 0)):
+            hostcheck.hc_set_wide_nodes(wide)
+            hostcheck.hc_set_origin_skip(skip)
+            out = np.zeros((h, w, 3), np.float32)
+            rays = (C.c_ulonglong * 2)()
+            hostcheck.hc_render(w, h, 0, 8, 32, 1, 0, 4, P(out), rays)
+            outs.append((out, rays[0], rays[1]))
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and outs[0][1:] == o[1:]
     finally:
+        hostcheck.hc_set_origin_skip(1)
         hostcheck.hc_set_wide_nodes(0)
         hostcheck.hc_scene_cornell()
 
