@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
       } else {
         const uint64_t carried = ((uint64_t)m.y << 32) | (uint64_t)m.x;
         PathState ps;
-        generate_path(p.cam, sl.x, sl.y, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
+        generate_path(p.cam, make_rand_ctx(sl.x, sl.y, 0, p.frame), hash_sample_index(p, sl, local), p.width, p.height,
                       start_seed(p, sl, local, carried), ps);
         store_state(p, pixel[k], ps);
         p.started[pixel[k]] = local + 1;
@@ -302,10 +302,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       const q4 hq = p.hits[i];
       const Hit h{(int)f2u(hq.x), hq.y, hq.z, hq.w};
       const Slot sl = decode_slot(p, pixel);
-      RandCtx rc;
-      rc.px = sl.x;
-      rc.py = sl.y;
-      rc.frame = p.frame;
+      RandCtx rc = make_rand_ctx(sl.x, sl.y, 0, p.frame);
       rc.s = ps_dim(ps) < 2u ? hash_sample_index(p, sl, p.started[pixel] - 1) : 0;
       shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
       seed_after = ps.seed;
@@ -445,10 +442,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
       const Slot sl = decode_slot(p, pixel);
       keep = (ps.flags & (kAlive | kFoldPending)) || local < sl.count;
       if (keep) {
-        RandCtx rc;
-        rc.px = sl.x;
-        rc.py = sl.y;
-        rc.frame = p.frame;
+        RandCtx rc = make_rand_ctx(sl.x, sl.y, 0, p.frame);  // the pixel's noise shift: once per launch
         for (int b = 0; b < bounces; ++b) {
           PT_PROF(PF_BOUNCE);
           if (!(ps.flags & kAlive)) {
@@ -461,7 +455,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
               ps.flags &= ~kFoldPending;
             }
             if (local >= sl.count) { keep = false; break; }
-            generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
+            generate_path(p.cam, rc, hash_sample_index(p, sl, local), p.width, p.height,
                           start_seed(p, sl, local, ps.seed), ps);
             local++;
           }
@@ -579,9 +573,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
       sl = decode_slot(p, pixel);
       keep = (ps.flags & (kAlive | kFoldPending)) || local < sl.count;
       entered = keep;
-      rc.px = sl.x;
-      rc.py = sl.y;
-      rc.frame = p.frame;
+      rc = make_rand_ctx(sl.x, sl.y, 0, p.frame);  // the pixel's noise shift: once per launch, not per draw
     }
     late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
     bool active = keep;
@@ -607,7 +599,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
           keep = false;
           active = false;
         } else {
-          generate_path(p.cam, rc.px, rc.py, hash_sample_index(p, sl, local), p.frame, p.width, p.height,
+          generate_path(p.cam, rc, hash_sample_index(p, sl, local), p.width, p.height,
                         start_seed(p, sl, local, ps.seed), ps);
           local++;
         }
@@ -994,7 +986,7 @@ __global__ void __launch_bounds__(256) k_dbg_shade(SceneView sc, GuideView gv, i
     ps.prev_pdf = r.prev_pdf_bsdf;
     const uint32_t dim = r.rng_dim < 2 ? (uint32_t)r.rng_dim : 2u;
     ps.flags = ((uint32_t)r.depth & kDepthMask) | (dim << kDimShift) | (r.prev_pdf_valid ? kPrevValid : 0u) | kAlive;
-    const RandCtx rc{r.px, r.py, r.sample, frame};
+    const RandCtx rc = make_rand_ctx(r.px, r.py, r.sample, frame);
     Hit h{prim[i], 0.f, b1[i], b2[i]};  // barycentrics arrive in the order the triangle was given
     if (h.prim >= 0) to_record_order(sc.shade[h.prim].corner_order, h.b1, h.b2);
     ShadowRay sr;

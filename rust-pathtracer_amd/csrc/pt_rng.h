@@ -24,17 +24,26 @@ PT_HD uint32_t hash_u32(uint32_t x) {
   return x;
 }
 
-// optix_device.cu:15-17, 176-185: R2 sequence with a per-pixel Cranley-Patterson shift.
-PT_HD void blue_noise(int x, int y, int s, int frame, float& u, float& v) {
+// optix_device.cu:15-17, 176-185: R2 sequence with a per-pixel Cranley-Patterson shift.  The shift depends
+// on the pixel and the frame only, so a kernel that works on one pixel for a while computes it once
+// (pixel_shift) and derives each sample's pair from it (blue_noise_shifted); blue_noise is the two together.
+PT_HD void pixel_shift(int x, int y, int frame, float& rx, float& ry) {
   const float inv_u16 = 1.0f / 65536.0f;
+  uint32_t h = hash_u32((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)frame * 26699u);
+  rx = (float)(h & 0xffffu) * inv_u16;
+  ry = (float)(h >> 16) * inv_u16;
+}
+PT_HD void blue_noise_shifted(float rx, float ry, int s, float& u, float& v) {
   const float inv_plastic = 1.0f / 1.32471795724474602596f;
   const float inv_plastic_sqr = 1.0f / (1.32471795724474602596f * 1.32471795724474602596f);
-  uint32_t h = hash_u32((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)frame * 26699u);
-  float rx = (float)(h & 0xffffu) * inv_u16;
-  float ry = (float)(h >> 16) * inv_u16;
   float fs = (float)s + 0.5f;
   u = fract_pos(rx + fs * inv_plastic);
   v = fract_pos(ry + fs * inv_plastic_sqr);
+}
+PT_HD void blue_noise(int x, int y, int s, int frame, float& u, float& v) {
+  float rx, ry;
+  pixel_shift(x, y, frame, rx, ry);
+  blue_noise_shifted(rx, ry, s, u, v);
 }
 
 // optix_device.cu:187-190: triangle-filter warp to [-1,1]

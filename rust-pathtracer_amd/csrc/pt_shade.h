@@ -48,9 +48,18 @@ struct ShadowRay {
   uint32_t origin;  // 1 + primitive it leaves (always known: NEE needs cosS > 0)
 };
 
+// What next_rand needs to know about the path's pixel and sample: the sample index that feeds the R2
+// sequence and the pixel's Cranley-Patterson shift (pixel_shift).
 struct RandCtx {
-  int px, py, s, frame;
+  int px, py, s;
+  float rx, ry;
 };
+PT_HD RandCtx make_rand_ctx(int px, int py, int s, int frame) {
+  RandCtx rc;
+  rc.px = px; rc.py = py; rc.s = s;
+  pixel_shift(px, py, frame, rc.rx, rc.ry);
+  return rc;
+}
 
 // optix_device.cu:198-209: the first two dimensions of a path reuse the blue-noise pair
 // that jittered the pixel; every later draw is PCG.
@@ -58,7 +67,7 @@ PT_HD float next_rand(PathState& ps, const RandCtx& rc) {
   const uint32_t dim = ps_dim(ps);
   if (dim < 2u) {
     float u, v;
-    blue_noise(rc.px, rc.py, rc.s, rc.frame, u, v);
+    blue_noise_shifted(rc.rx, rc.ry, rc.s, u, v);
     ps.flags += 1u << kDimShift;
     return dim == 0u ? u : v;
   }
@@ -355,10 +364,11 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
 
 // optix_device.cu:955-969: start sample `s` of pixel (x,y).  The caller supplies the PCG
 // state the sample starts from.
-PT_HD void generate_path(const CameraView& cam, int x, int y, int s, int frame, int width, int height, uint64_t seed,
+PT_HD void generate_path(const CameraView& cam, const RandCtx& rc, int s, int width, int height, uint64_t seed,
                          PathState& ps) {
+  const int x = rc.px, y = rc.py;
   float u, v;
-  blue_noise(x, y, s, frame, u, v);
+  blue_noise_shifted(rc.rx, rc.ry, s, u, v);
   const float jx = sample_tri(u), jy = sample_tri(v);  // optix_device.cu:192-196
   ps.o = ld3(cam.eye);
   ps.d = camera_dir(cam, x, y, jx, jy, width, height);

@@ -171,7 +171,7 @@ void hc_shade(int n, HcRec* recs, const int* prim, const float* b1, const float*
     ps.sum = mk3(0.f); ps.seed = r.seed; ps.prev_pdf = r.prev_pdf_bsdf;
     const uint32_t dim = r.rng_dim < 2 ? (uint32_t)r.rng_dim : 2u;
     ps.flags = ((uint32_t)r.depth & kDepthMask) | (dim << kDimShift) | (r.prev_pdf_valid ? kPrevValid : 0u) | kAlive;
-    RandCtx rc{r.px, r.py, r.sample, frame};
+    RandCtx rc = make_rand_ctx(r.px, r.py, r.sample, frame);
     Hit h{prim[i], 0.f, b1[i], b2[i]};
     if (h.prim >= 0) to_record_order(g_sv.shade[h.prim].corner_order, h.b1, h.b2);
     ShadowRay sr;
@@ -214,8 +214,8 @@ void hc_render(int w, int h, int sample_begin, int sample_count, int max_depth, 
           uint64_t start = strict ? ((local & 3) == 0 ? pixel_seed(frame, pixel) : seed)
                                   : (local == 0 ? chunk_seed(frame, pixel, sample_begin) : seed);
           PathState ps;
-          generate_path(g_cam, x, y, s, frame, w, h, start, ps);
-          RandCtx rc{x, y, s, frame};
+          RandCtx rc = make_rand_ctx(x, y, s, frame);
+          generate_path(g_cam, rc, s, w, h, start, ps);
           ShadeParams sp{frame, max_depth, g_guiding};
           while (ps.flags & kAlive) {
             LocalStack st;
