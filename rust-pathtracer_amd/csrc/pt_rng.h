@@ -64,8 +64,8 @@ PT_HD uint64_t chunk_seed(int frame, uint32_t dst, int begin) {
 
 // optix_device.cu:890-900
 PT_HD f3 camera_dir(const CameraView& cam, int x, int y, float jx, float jy, int width, int height) {
-  float fx = ((float)x + 0.5f + jx) / (float)width;
-  float fy = ((float)y + 0.5f + jy) / (float)height;
+  float fx = ((float)x + 0.5f + jx) * rcp((float)width);
+  float fy = ((float)y + 0.5f + jy) * rcp((float)height);
   fx = clamp01(fx);
   fy = clamp01(fy);
   float dx = 2.0f * fx - 1.0f, dy = 1.0f - 2.0f * fy;

@@ -259,8 +259,8 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
       const f3 L = P - ps.o;
       const float dist2 = fmaxf(dot(L, L), 1e-6f);
       const float cosL = fmaxf(0.0f, dot(light_n, -dir));
-      const float pdf_light = dist2 / (cosL * area);
-      const float w_bsdf = ps.prev_pdf / (ps.prev_pdf + pdf_light);
+      const float pdf_light = dist2 * rcp(cosL * area);
+      const float w_bsdf = ps.prev_pdf * rcp(ps.prev_pdf + pdf_light);
       emission = emission * w_bsdf;
     }
     radiance = emission;
@@ -344,7 +344,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
       const float final_pdf = used_guiding ? p_guided : p_bsdf;
       f3 T = ps.T * kd;
       if (used_guiding) T = T * lobe_rgb;
-      ps.T = T * (cosTheta / (kPi * final_pdf * diff_prob));
+      ps.T = T * (cosTheta * rcp(kPi * final_pdf * diff_prob));
       ps.prev_pdf = final_pdf * diff_prob;
       ps.flags |= kPrevValid;
     }
