@@ -24,13 +24,47 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# Algorithmic work per ray used for the roofline figures (fixed by construction of the
-# wavefront records: 68 B path state read + written, 16 B hit record, 44 B shadow record and
-# queue indices per path segment of one radiance + at most one shadow ray = 332 B / 2 rays).
+# Work per ray used for the roofline figures.
+# FLOP_PER_RAY: fp32 operations of one BVH query plus its share of a shading step, counted on the source
+# (about 10 box tests x 20 + 6 item tests x 35 per query, 350 per opaque shading step; transcendentals as 1).
+# BYTES_PER_RAY: what a wavefront formulation moves through HBM per ray (68 B path state read + written, 16 B
+# hit record, 44 B shadow record and queue indices per path segment of one radiance + at most one shadow ray
+# = 332 B / 2 rays).  The staged pipeline moves these bytes; the fused kernel keeps a path in registers for 16
+# bounces and the scene in LDS, so for it the figure is an equivalent, not traffic, and its bound is the vector ALU.
 BYTES_PER_RAY = 166.0
 FLOP_PER_RAY = 600.0
 HBM_PEAK_GBS = 8000.0
 VALU_PEAK_TFLOPS = 157.3
+
+
+def boundary_timings(ptamd, L, w, h, spp, max_depth):
+    """The reference's own entry point at the bench configuration (render + finalise + copy into pinned host
+    memory from optix_alloc_host), and the 4K demosaic kernel; reported beside the headline, not part of it."""
+    import ctypes as C
+    out = {}
+    n = w * h * 3
+    host = L.optix_alloc_host(n * 4)
+    buf = C.cast(host, C.POINTER(C.c_float))
+    t = time.perf_counter()
+    rc = L.optix_render_rgb(w, h, spp, max_depth, 0.0, 32, buf)
+    out["boundary_ms"] = (time.perf_counter() - t) * 1e3
+    out["boundary_device_ms"] = L.pt_last_render_ms()
+    assert rc == 0
+    img = np.ctypeslib.as_array(buf, shape=(n,))
+    out["boundary_image_mean"] = float(img.mean())
+    L.optix_free_host(host)
+    dw, dh = 3840, 2160
+    raw = torch.rand(dw * dh, dtype=torch.float32, device="cuda")
+    rgb = torch.empty(dw * dh * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for algo, name in ((0, "demosaic_gradient_us_4k"), (1, "demosaic_bilinear_us_4k")):
+        L.pt_demosaic_device(raw.data_ptr(), dw, dh, 0, algo, rgb.data_ptr())  # warm-up
+        before = ptamd.kernel_stats(ptamd.K_DEMOSAIC)
+        for _ in range(5):
+            L.pt_demosaic_device(raw.data_ptr(), dw, dh, 0, algo, rgb.data_ptr())
+        after = ptamd.kernel_stats(ptamd.K_DEMOSAIC)
+        out[name] = (after["total_ms"] - before["total_ms"]) / 5 * 1e3
+    return out
 
 
 def main():
@@ -45,6 +79,7 @@ def main():
     ap.add_argument("--pipeline", choices=["fused", "staged"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=48)
+    ap.add_argument("--no-boundary", action="store_true", help="skip the optix_render_rgb / demosaic timings")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,8 +157,8 @@ def main():
         rays_per_launch = ((rr + rs) if args.pipeline == "fused" else rr) / max(kst["launches"], 1)
         achieved_gbs = BYTES_PER_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         achieved_tflops = FLOP_PER_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        # HBM bytes per launch and VALU pipe occupancy come from the committed PMC passes of this same
-        # command (profiles/): counters cannot be read from inside the timed run
+        # HBM bytes per launch and the VALU counters come from the committed PMC passes of this same command
+        # (profiles/pmc_traffic.json, written by tools/r02_profiles.py): counters cannot be read inside the timed run
         traffic, pmc = None, {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and (w, h, spp) == (1920, 1080, 1024):
@@ -132,6 +167,20 @@ def main():
                 traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
                 traffic, pmc = None, {}
+        common = {"kernel": ptamd.KERNEL_NAMES[kid], "avg_launch_ms": avg_ms, "launches": kst["launches"],
+                  "rays_per_launch": rays_per_launch, "traffic": traffic}
+        hbm = dict(common, bound="hbm", achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                   frac=achieved_gbs / HBM_PEAK_GBS, bytes_per_ray=BYTES_PER_RAY)
+        cyc = pmc.get("simd_cycles_per_valu_inst")
+        valu = dict(common, bound="valu", achieved=achieved_tflops, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved_tflops / VALU_PEAK_TFLOPS, flop_per_ray=FLOP_PER_RAY,
+                    # SIMD cycles that pass per vector instruction issued, against what this kernel's instruction
+                    # mix costs to issue (tools/isa_cost.py on the kernel's ISA with the per-opcode costs measured by
+                    # tools/valu_ops.hip: 2.4 / 4.2 / 8.2 cycles); lane_util = active lanes per vector instruction / 64
+                    simd_cycles_per_valu_inst=cyc, issue_cost_cycles_per_valu_inst=pmc.get("issue_cost_cycles_per_valu_inst"),
+                    issue_util=(pmc.get("issue_cost_cycles_per_valu_inst") / cyc) if cyc and pmc.get("issue_cost_cycles_per_valu_inst") else None,
+                    lane_util=pmc.get("valu_lane_utilisation"), valu_insts_per_ray=pmc.get("valu_insts_per_ray"))
+        fused = args.pipeline == "fused"
         result = {
             "metric": "Mrays/s at 1080p default scene (radiance + shadow rays)",
             "value": rays_all / elapsed / 1e6,
@@ -150,16 +199,12 @@ def main():
             "spp_per_s": spp * world * args.steps / elapsed,
             "paths_per_s": float(w) * h * spp * world * args.steps / elapsed,
             "rays_per_path": rays_all / (float(w) * h * spp * world * args.steps),
-            "roofline": {"bound": "hbm", "kernel": ptamd.KERNEL_NAMES[kid], "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": kst["launches"], "rays_per_launch": rays_per_launch,
-                         "bytes_per_ray": BYTES_PER_RAY},
-            "roofline_valu": {"bound": "valu", "achieved": achieved_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved_tflops / VALU_PEAK_TFLOPS, "flop_per_ray": FLOP_PER_RAY,
-                              "pmc_simd_cycles_per_valu_inst": pmc.get("simd_cycles_per_valu_inst"),
-                              "pmc_lane_utilisation": pmc.get("valu_lane_utilisation"),
-                              "pmc_valu_insts_per_ray": pmc.get("valu_insts_per_ray")},
+            # the fused kernel is bound by vector-instruction issue, the staged kernels by HBM
+            "roofline": valu if fused else hbm,
+            ("roofline_hbm_equiv" if fused else "roofline_valu"): hbm if fused else valu,
         }
+        if world == 1 and not args.no_boundary:
+            result.update(boundary_timings(ptamd, L, w, h, spp, args.max_depth))
         if world == 1 and not args.no_cpu_baseline:
             import orc
             cores = min(os.cpu_count() or 1, 16)

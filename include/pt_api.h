@@ -247,11 +247,13 @@ PT_EXPORT double pt_last_render_ms(void);
  * pt_scene_synthetic replaces it by the box plus a seeded grid of triangulated spheres
  * (about n_objects * 20 * 4^subdiv triangles) to stress BVH traversal out of HBM;
  * pt_scene_triangles installs caller geometry (materials: 11 floats per triangle in
- * HitData order, optix_wrapper.cpp:162-170; NULL = white diffuse).  pt_scene_cornell
+ * HitData order, optix_wrapper.cpp:162-170; NULL = white diffuse) and returns 0, or -1 with the reason on
+ * stderr and the scene unchanged when a count is negative, an array NULL, an index >= n_vertices or a value not
+ * finite.  pt_scene_cornell
  * restores the default.  All take effect at the next render. */
 PT_EXPORT void pt_scene_cornell(void);
 PT_EXPORT void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv);
-PT_EXPORT void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
+PT_EXPORT int  pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                                   const float* materials11);
 /* pgl_samples_add_surface for `count` records in the layout guiding_map_train_samples returns (the host loop
  * of src/guiding.rs:196-219 in one call); used by multi-GPU hosts that gather every rank's ring on one rank. */

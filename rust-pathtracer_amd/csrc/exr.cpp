@@ -119,23 +119,36 @@ extern "C" int pt_read_exr(const char* path, int* w_out, int* h_out, float* rgb,
   int w = 0, h = 0, xmin = 0, ymin = 0;
   int compression = -1;
   std::vector<std::string> channels;
+  // a NUL-terminated string starting at p, entirely inside [p, limit): its length, or -1
+  auto cstr_len = [&](size_t p, size_t limit) -> long {
+    for (size_t q = p; q < limit && q < buf.size(); ++q)
+      if (buf[q] == 0) return (long)(q - p);
+    return -1;
+  };
   for (;;) {
     if (!need(1)) return -2;
     if (buf[pos] == 0) { pos++; break; }
-    std::string name(reinterpret_cast<const char*>(&buf[pos]));
-    pos += name.size() + 1;
-    std::string type(reinterpret_cast<const char*>(&buf[pos]));
-    pos += type.size() + 1;
+    long len = cstr_len(pos, buf.size());
+    if (len < 0) return -2;
+    std::string name(reinterpret_cast<const char*>(&buf[pos]), (size_t)len);
+    pos += (size_t)len + 1;
+    len = cstr_len(pos, buf.size());
+    if (len < 0) return -2;
+    std::string type(reinterpret_cast<const char*>(&buf[pos]), (size_t)len);
+    pos += (size_t)len + 1;
     if (!need(4)) return -2;
     int32_t size;
     memcpy(&size, &buf[pos], 4);
     pos += 4;
     if (size < 0 || !need((size_t)size)) return -2;
+    const size_t end = pos + (size_t)size;
     if (name == "channels") {
       size_t p = pos;
-      while (p < pos + (size_t)size && buf[p] != 0) {
-        std::string cn(reinterpret_cast<const char*>(&buf[p]));
-        p += cn.size() + 1;
+      while (p < end && buf[p] != 0) {
+        const long cl = cstr_len(p, end);
+        if (cl < 0 || p + (size_t)cl + 1 + 16 > end) return -2;  // name, then 16 bytes: type, linear, sampling
+        std::string cn(reinterpret_cast<const char*>(&buf[p]), (size_t)cl);
+        p += (size_t)cl + 1;
         int32_t ptype;
         memcpy(&ptype, &buf[p], 4);
         if (ptype != 2) return -3;
@@ -143,15 +156,19 @@ extern "C" int pt_read_exr(const char* path, int* w_out, int* h_out, float* rgb,
         channels.push_back(cn);
       }
     } else if (name == "compression") {
+      if (size < 1) return -2;
       compression = buf[pos];
     } else if (name == "dataWindow") {
+      if (size < 16) return -2;
       int32_t b[4];
       memcpy(b, &buf[pos], 16);
       xmin = b[0]; ymin = b[1];
-      w = b[2] - b[0] + 1;
-      h = b[3] - b[1] + 1;
+      const long long ww = (long long)b[2] - b[0] + 1, hh = (long long)b[3] - b[1] + 1;
+      if (ww <= 0 || hh <= 0 || ww > (1 << 20) || hh > (1 << 20)) return -3;
+      w = (int)ww;
+      h = (int)hh;
     }
-    pos += (size_t)size;
+    pos = end;
   }
   if (compression != 0 || w <= 0 || h <= 0 || channels.size() != 3) return -3;
   int ci[3] = {-1, -1, -1};  // position of R, G, B in the stored order
@@ -171,7 +188,7 @@ extern "C" int pt_read_exr(const char* path, int* w_out, int* h_out, float* rgb,
     uint64_t off;
     memcpy(&off, &buf[pos], 8);
     pos += 8;
-    if (off + 8 + line_bytes > buf.size()) return -2;
+    if (buf.size() < 8 + line_bytes || off > buf.size() - 8 - line_bytes) return -2;  // no wrap-around for a huge offset
     int32_t yy;
     memcpy(&yy, &buf[off], 4);
     const int row = yy - ymin;

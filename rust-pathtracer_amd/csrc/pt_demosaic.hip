@@ -3,7 +3,9 @@
 //
 // The reference runs six in-place passes over three colour planes.  In every pass a site
 // writes only itself and reads only sites that the pass does not write (or itself, through
-// border clamping, before its own write), so each pass is a data-parallel gather.  Here:
+// border clamping, before its own write), so each pass is a data-parallel gather.  The shipped
+// kernel, k_gradient_fused, runs them all on one tile in LDS.  The pass-by-pass form it fuses is kept
+// for comparison in builds with -DPT_DEMOSAIC_PASSES (the profiling library) only:
 //   k_green   raw            -> g     (passes 0+1: plane split folded into the reads)
 //   k_rb_at_g raw, g         -> r, b  (pass 2; red/blue sites carry their raw value / 0)
 //   k_rb_diag r, g, b        -> r, b  (pass 3, in place)
@@ -41,6 +43,7 @@ __device__ __forceinline__ float plane_raw(const float* raw, int w, int h, int x
   return cfa_at(xx, yy, pattern) == c ? raw[(size_t)yy * w + xx] : 0.0f;
 }
 
+#ifdef PT_DEMOSAIC_PASSES
 // src/main.rs:205-237
 __global__ void k_green(const float* raw, float* g, int w, int h, int pattern) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -138,6 +141,8 @@ __global__ void k_combine(const float* r, const float* g, const float* b, float*
   out[3 * i + 1] = fmaxf(g0, 0.0f);
   out[3 * i + 2] = fmaxf(g0 + bg2, 0.0f);
 }
+
+#endif  // PT_DEMOSAIC_PASSES
 
 // ------------------------------------------------------------------ fused gradient method
 // The four passes above move about 70 bytes per pixel through HBM (three intermediate planes written
@@ -324,24 +329,26 @@ void launch_demosaic(const float* d_raw, float* d_out, float* d_tmp, int w, int 
     PT_KCHECK2();
     return;
   }
-  static const bool passes = getenv("PT_DEMOSAIC_PASSES") != nullptr;  // the four-pass form, for comparison
-  if (!passes) {
-    const dim3 tiles((unsigned)((w + kTW - 1) / kTW), (unsigned)((h + kTH - 1) / kTH));
-    k_gradient_fused<<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, pattern);
+#ifdef PT_DEMOSAIC_PASSES
+  if (getenv("PT_DEMOSAIC_PASSES") != nullptr && d_tmp) {  // the four-pass form, for comparison
+    const size_t n = (size_t)w * (size_t)h;
+    float* g = d_tmp;
+    float* r = d_tmp + n;
+    float* b = d_tmp + 2 * n;
+    k_green<<<grid, block, 0, s>>>(d_raw, g, w, h, pattern);
+    PT_KCHECK2();
+    k_rb_at_g<<<grid, block, 0, s>>>(d_raw, g, r, b, w, h, pattern);
+    PT_KCHECK2();
+    k_rb_diag<<<grid, block, 0, s>>>(g, r, b, w, h, pattern);
+    PT_KCHECK2();
+    k_combine<<<grid, block, 0, s>>>(r, g, b, d_out, w, h);
     PT_KCHECK2();
     return;
   }
-  const size_t n = (size_t)w * (size_t)h;
-  float* g = d_tmp;
-  float* r = d_tmp + n;
-  float* b = d_tmp + 2 * n;
-  k_green<<<grid, block, 0, s>>>(d_raw, g, w, h, pattern);
-  PT_KCHECK2();
-  k_rb_at_g<<<grid, block, 0, s>>>(d_raw, g, r, b, w, h, pattern);
-  PT_KCHECK2();
-  k_rb_diag<<<grid, block, 0, s>>>(g, r, b, w, h, pattern);
-  PT_KCHECK2();
-  k_combine<<<grid, block, 0, s>>>(r, g, b, d_out, w, h);
+#endif
+  (void)d_tmp;
+  const dim3 tiles((unsigned)((w + kTW - 1) / kTW), (unsigned)((h + kTH - 1) / kTH));
+  k_gradient_fused<<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, pattern);
   PT_KCHECK2();
 }
 

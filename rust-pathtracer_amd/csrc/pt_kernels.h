@@ -99,7 +99,8 @@ void launch_add_counts(const int* started, float* count, uint32_t npx, int chunk
 void launch_mosaic(const float* rgb, float* raw, int w, int h, int pattern, float divisor, hipStream_t s);
 
 // demosaic passes (pt_demosaic.hip)
-void launch_demosaic(const float* d_raw, float* d_out, float* d_tmp /* 7*w*h floats */, int w, int h, int pattern,
+// d_tmp: 3*w*h floats of scratch for the pass-by-pass form of builds with -DPT_DEMOSAIC_PASSES, else unused (may be null)
+void launch_demosaic(const float* d_raw, float* d_out, float* d_tmp, int w, int h, int pattern,
                      int algo, hipStream_t s);
 
 // stage-level debug kernels

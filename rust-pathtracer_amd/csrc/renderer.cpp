@@ -761,7 +761,7 @@ State::~State() {
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);
   dev_free(shared_acc); dev_free(shared_acc2); dev_free(shared_n);
-  dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_demosaic_tmp);
+  dev_free(d_out_rgb); dev_free(d_out_bayer);
   dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid);
   if (h_counters) (void)hipHostFree(h_counters);
   for (int i = 0; i < 2; ++i) if (ev_slot[i]) (void)hipEventDestroy(ev_slot[i]);
@@ -1026,11 +1026,23 @@ int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, int algo, 
   if (!d_raw || !d_out_rgb) return -1;
   HIP_CHECK(hipSetDevice(device_index()));
   const size_t n = (size_t)w * (size_t)h;
-  float* tmp = dev_alloc<float>(3 * n);
+  float* tmp = nullptr;
+#ifdef PT_DEMOSAIC_PASSES
+  static float* s_tmp = nullptr;  // comparison builds only: scratch of the pass-by-pass form, grown on demand
+  static size_t s_tmp_n = 0;
+  if (getenv("PT_DEMOSAIC_PASSES") && s_tmp_n < 3 * n) {
+    dev_free(s_tmp);
+    s_tmp = dev_alloc<float>(3 * n);
+    s_tmp_n = 3 * n;
+  }
+  tmp = s_tmp;
+#endif
   hipStream_t st = g_handle ? g_handle->stream : nullptr;
-  hipEvent_t a, b;
-  HIP_CHECK(hipEventCreate(&a));
-  HIP_CHECK(hipEventCreate(&b));
+  static hipEvent_t a = nullptr, b = nullptr;  // created once: a call costs two event records and the kernel
+  if (!a) {
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+  }
   HIP_CHECK(hipEventRecord(a, st));
   launch_demosaic(d_raw, d_out_rgb, tmp, w, h, pattern, algo, st);
   HIP_CHECK(hipEventRecord(b, st));
@@ -1041,9 +1053,6 @@ int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, int algo, 
   g_kstats[PT_K_DEMOSAIC].timed++;
   g_kstats[PT_K_DEMOSAIC].launches++;
   g_kstats[PT_K_DEMOSAIC].work += n;
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  dev_free(tmp);
   return 0;
 }
 
@@ -1119,11 +1128,26 @@ void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv) {
   g_scene_init = true;
   g_scene_version++;
 }
-void pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
-                        const float* materials11) {
+int pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
+                       const float* materials11) {
+  // the arrays are caller memory: check them before the BVH builder indexes with them
+  const char* why = nullptr;
+  if (n_vertices < 0 || n_triangles < 0) why = "negative count";
+  else if ((n_vertices > 0 && !vertices) || (n_triangles > 0 && !indices)) why = "null array";
+  for (size_t k = 0; !why && k < 3 * (size_t)n_triangles; ++k)
+    if (indices[k] >= (uint32_t)n_vertices) why = "vertex index out of range";
+  for (size_t k = 0; !why && k < 3 * (size_t)n_vertices; ++k)
+    if (!std::isfinite(vertices[k])) why = "vertex coordinate not finite";
+  for (size_t k = 0; !why && materials11 && k < 11 * (size_t)n_triangles; ++k)
+    if (!std::isfinite(materials11[k])) why = "material value not finite";
+  if (why) {
+    fprintf(stderr, "[pt_hip] pt_scene_triangles: %s; the current scene is kept\n", why);
+    return -1;
+  }
   g_scene = make_from_triangles(vertices, n_vertices, indices, n_triangles, materials11);
   g_scene_init = true;
   g_scene_version++;
+  return 0;
 }
 void pt_scene_counts(int* n_vertices, int* n_triangles) {
   HostScene& hs = scene();

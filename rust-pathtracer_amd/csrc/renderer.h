@@ -77,7 +77,6 @@ struct State {
   // outputs
   float* d_out_rgb = nullptr;
   float* d_out_bayer = nullptr;
-  float* d_demosaic_tmp = nullptr;
 
   // guiding
   TrainRec* d_train = nullptr;

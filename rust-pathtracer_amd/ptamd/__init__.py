@@ -107,7 +107,7 @@ SIGNATURES = {
     "pt_get_sample_counts": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pt_scene_cornell": (None, []),
     "pt_scene_synthetic": (None, [C.c_uint32, C.c_int, C.c_int]),
-    "pt_scene_triangles": (None, [_fp, C.c_int, _u32p, C.c_int, _fp]),
+    "pt_scene_triangles": (C.c_int, [_fp, C.c_int, _u32p, C.c_int, _fp]),
     "pt_set_bvh_pairing": (None, [C.c_int]),
     "pt_scene_load_obj": (C.c_int, [C.c_char_p]),
     "pt_scene_counts": (None, [_ip, _ip]),

@@ -457,6 +457,64 @@ def test_exr_round_trip(pt, tmp_path):
     assert pt.lib().pt_write_exr(b"/nonexistent_dir/x.exr", 1, 1, P(np.zeros(3, np.float32)), 1.0) == -1
 
 
+def test_exr_reader_rejects_damaged_files(pt, tmp_path):
+    """Truncated or corrupted files: an error code, never a read outside the file."""
+    L = pt.lib()
+    img = np.random.default_rng(1).uniform(0, 4, (6, 7, 3)).astype(np.float32)
+    good = str(tmp_path / "good.exr")
+    assert pt.write_exr(good, img) == 0
+    raw = open(good, "rb").read()
+    w, h = C.c_int(), C.c_int()
+    out = np.zeros(img.size, np.float32)
+    bad = str(tmp_path / "bad.exr")
+    rng = np.random.default_rng(2)
+    cuts = list(range(0, 40)) + [len(raw) // 3, len(raw) // 2, len(raw) - 1]
+    for cut in cuts:  # every prefix that ends inside the header, and a few inside the pixel data
+        open(bad, "wb").write(raw[:cut])
+        assert L.pt_read_exr(bad.encode(), C.byref(w), C.byref(h), P(out), out.size) != 0
+    header_end = raw.index(b"screenWindowWidth") + 40
+    for _ in range(300):  # random byte damage in the header: any return code, no crash
+        b = bytearray(raw)
+        for k in rng.integers(8, header_end, 3):
+            b[k] = int(rng.integers(0, 256))
+        open(bad, "wb").write(bytes(b))
+        L.pt_read_exr(bad.encode(), C.byref(w), C.byref(h), P(out), out.size)
+    b = bytearray(raw)  # a scanline offset far outside the file
+    table = len(raw) - 6 * (8 + 7 * 12) - 6 * 8
+    b[table:table + 8] = (2**64 - 4).to_bytes(8, "little")
+    open(bad, "wb").write(bytes(b))
+    assert L.pt_read_exr(bad.encode(), C.byref(w), C.byref(h), P(out), out.size) == -2
+    assert np.array_equal(pt.read_exr(good), img)
+
+
+def test_scene_triangles_checks_its_input(pt):
+    """pt_scene_triangles takes caller memory: bad counts, null arrays, indices past the vertex array and
+    non-finite values are refused (-1) and the scene stays what it was."""
+    L = pt.lib()
+    L.pt_scene_cornell()
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    I = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    before = pt.scene_arrays()
+    u32 = C.POINTER(C.c_uint32)
+    assert L.pt_scene_triangles(P(V), -1, I.ctypes.data_as(u32), 2, None) == -1
+    assert L.pt_scene_triangles(None, 4, I.ctypes.data_as(u32), 2, None) == -1
+    assert L.pt_scene_triangles(P(V), 4, None, 2, None) == -1
+    bad = I.copy()
+    bad[1, 2] = 4
+    assert L.pt_scene_triangles(P(V), 4, bad.ctypes.data_as(u32), 2, None) == -1
+    nanv = V.copy()
+    nanv[2, 1] = np.nan
+    assert L.pt_scene_triangles(P(nanv), 4, I.ctypes.data_as(u32), 2, None) == -1
+    M = np.full((2, 11), np.inf, np.float32)
+    assert L.pt_scene_triangles(P(V), 4, I.ctypes.data_as(u32), 2, P(M)) == -1
+    after = pt.scene_arrays()
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+    assert L.pt_scene_triangles(P(V), 4, I.ctypes.data_as(u32), 2, None) == 0
+    assert pt.scene_arrays()[1].shape == (2, 3)
+    assert L.pt_scene_triangles(P(V), 0, I.ctypes.data_as(u32), 0, None) == 0  # an empty scene is a scene
+    L.pt_scene_cornell()
+
+
 def test_pgl_stand_in_trainer(pt):
     """ABI and ownership of the pgl_* calls (openpgl_bridge.h:7-33); the trainer itself is not OpenPGL."""
     L = pt.lib()
