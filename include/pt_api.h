@@ -156,6 +156,20 @@ PT_EXPORT int  pt_get_defer_shadow(void);
 /* Select the HIP device the next renderer is created on (default 0, or env PT_DEVICE). */
 PT_EXPORT void pt_set_device(int device);
 
+/* Several GPUs behind the reference's own entry points (no counterpart in the reference, which drives one device:
+ * optix_wrapper.cpp:788,1138).  With n > 1 (or the environment variable PT_GPUS=n), optix_render_rgb and
+ * optix_render_bayer_f32 split every converge-mode render by sample index into n shards -- shard d renders global
+ * samples [d*spp/n, (d+1)*spp/n) of every pixel (pt_shard_range), exactly what rank d of a multi-process render
+ * renders through pt_render_accumulate_device -- on GPUs first, first + 1, ... (modulo the number of GPUs: more
+ * shards than GPUs is allowed and changes only the speed), one host thread per shard; the shards' per-pixel totals
+ * are copied to the first GPU (peer copies over xGMI), added there in shard order and divided by the samples
+ * taken, so a caller of optix_render_rgb sees one image and nothing else changes.  Adaptive renders stop each
+ * shard's pixels on the shard's own statistics.  Scene, camera, Bayer pattern and guiding snapshot are replicated;
+ * guiding_map_train_samples returns the records of all shards' rings.  Strict mode is never sharded. */
+PT_EXPORT void pt_set_device_count(int n);
+PT_EXPORT int  pt_get_device_count(void);
+PT_EXPORT void pt_shard_range(int spp, int n_shards, int shard, int* begin, int* count);
+
 /* Frame counter: the reference increments Params.frame once per render call
  * (optix_wrapper.cpp:983); tests pin it.  The next render uses frame = value + 1. */
 PT_EXPORT void pt_set_frame(int frame);

@@ -93,6 +93,10 @@ int read_profile_counters(unsigned long long* out64);
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);
 // per pixel, over its `chunks` slots: mode 0 writes the mean (sum / samples), mode 1 adds the raw sums
 void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s);
+// one shard's totals per pixel {sum r, g, b, samples} over its chunks; and the mean over shard `own` and npeers more
+// (peers: npeers arrays of npx q4 one after the other), added in that order
+void launch_shard_sums(const q4* acc, const int* started, q4* sum4, uint32_t npx, int chunks, hipStream_t s);
+void launch_reduce_shards(const q4* own, const q4* peers, int npeers, float* out_rgb, uint32_t npx, hipStream_t s);
 // count[p] += samples the pixel took (over its chunks)
 void launch_add_counts(const int* started, float* count, uint32_t npx, int chunks, hipStream_t s);
 // mosaic: raw[p] = max(rgb[3p + ch(p)] / divisor, 0)

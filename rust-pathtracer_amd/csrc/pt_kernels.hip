@@ -812,6 +812,31 @@ __global__ void k_finalize(const q4* acc, const int* started, float* out, uint32
     }
   }
 }
+// Sample-sharded renders inside one process: a shard's per-pixel totals as {sum r, g, b, samples taken}, and
+// the mean over all shards, added up in shard order so the result does not depend on timing.
+__global__ void k_shard_sums(const q4* acc, const int* started, q4* sum4, uint32_t npx, int chunks) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    q4 a = acc[i];
+    int c = started[i];
+    for (int k = 1; k < chunks; ++k) {
+      const q4 b = acc[(size_t)k * npx + i];
+      a.x += b.x; a.y += b.y; a.z += b.z;
+      c += started[(size_t)k * npx + i];
+    }
+    sum4[i] = q4{a.x, a.y, a.z, (float)c};
+  }
+}
+__global__ void k_reduce_shards(const q4* own, const q4* peers, int npeers, float* out, uint32_t npx) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    q4 t = own[i];
+    for (int k = 0; k < npeers; ++k) {
+      const q4 b = peers[(size_t)k * npx + i];
+      t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+    }
+    const float inv = t.w > 0.0f ? 1.0f / t.w : 0.0f;
+    out[3 * i + 0] = t.x * inv; out[3 * i + 1] = t.y * inv; out[3 * i + 2] = t.z * inv;
+  }
+}
 __global__ void k_add_counts(const int* started, float* count, uint32_t npx, int chunks) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
     int c = 0;
@@ -920,6 +945,14 @@ void launch_expand_active(const uint32_t* active, uint32_t n_active, int chunks,
 }
 void launch_finalize(const q4* acc, const int* started, float* out_rgb, uint32_t npx, int chunks, int mode, hipStream_t s) {
   k_finalize<<<1024, 256, 0, s>>>(acc, started, out_rgb, npx, chunks, mode);
+  PT_KCHECK();
+}
+void launch_shard_sums(const q4* acc, const int* started, q4* sum4, uint32_t npx, int chunks, hipStream_t s) {
+  k_shard_sums<<<1024, 256, 0, s>>>(acc, started, sum4, npx, chunks);
+  PT_KCHECK();
+}
+void launch_reduce_shards(const q4* own, const q4* peers, int npeers, float* out_rgb, uint32_t npx, hipStream_t s) {
+  k_reduce_shards<<<1024, 256, 0, s>>>(own, peers, npeers, out_rgb, npx);
   PT_KCHECK();
 }
 void launch_add_counts(const int* started, float* count, uint32_t npx, int chunks, hipStream_t s) {

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 namespace pt {
 namespace {
@@ -34,6 +36,9 @@ HostScene g_scene;
 bool g_scene_init = false;
 uint64_t g_scene_version = 1;
 int g_timing_every = 0;
+int g_gpus = -1;                 // sample shards per render call; -1: read PT_GPUS on first use
+std::vector<State*> g_shards;    // shards 1, 2, ... (shard 0 is g_handle)
+std::mutex g_stats_mutex;        // ray totals are added from every shard's host thread
 KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
 int g_fused_bounces = 16;
@@ -264,9 +269,9 @@ int max_chunks_for(size_t px) {
 }
 
 // optix_wrapper.cpp:784-920
-State* make_state(int W, int H) {
+State* make_state(int W, int H, int device = -1) {
   State* s = new State();
-  s->device = device_index();
+  s->device = device >= 0 ? device : device_index();
   HIP_CHECK(hipSetDevice(s->device));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, s->device));
@@ -309,10 +314,16 @@ State* make_state(int W, int H) {
   return s;
 }
 
+void drop_shards() {
+  for (State* sh : g_shards) delete sh;
+  g_shards.clear();
+}
+
 // optix_wrapper.cpp:1087-1100
 State& ensure_handle(int w, int h) {
   if (!g_handle || w != g_last_w || h != g_last_h) {
     delete g_handle;
+    drop_shards();
     g_handle = make_state(w, h);
     g_last_w = w;
     g_last_h = h;
@@ -330,7 +341,8 @@ struct Timer {
   int kernel;
   bool on;
   hipEvent_t a = nullptr, b = nullptr;
-  Timer(State& st, int k, bool enabled, uint64_t work) : s(st), kernel(k), on(enabled) {
+  Timer(State& st, int k, bool enabled, uint64_t work) : s(st), kernel(k), on(enabled && !st.quiet) {
+    if (st.quiet) return;  // shards other than 0 run on other host threads: they leave the statistics alone
     g_kstats[k].launches++;
     g_kstats[k].work += work;
     if (on) {
@@ -522,8 +534,11 @@ struct RenderLoop {
     resolve_timers(s);
     unsigned long long rc[2];
     HIP_CHECK(hipMemcpy(rc, s.ray_counters, sizeof(rc), hipMemcpyDeviceToHost));
-    g_rays_total[0] += rc[0];
-    g_rays_total[1] += rc[1];
+    {
+      std::lock_guard<std::mutex> lock(g_stats_mutex);
+      g_rays_total[0] += rc[0];
+      g_rays_total[1] += rc[1];
+    }
     HIP_CHECK(hipMemset(s.ray_counters, 0, sizeof(rc)));
   }
 };
@@ -657,9 +672,97 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
   return rc;
 }
 
+int shard_setting() {
+  if (g_gpus < 0) {
+    const char* v = getenv("PT_GPUS");
+    g_gpus = v ? std::max(atoi(v), 1) : 1;
+  }
+  return g_gpus;
+}
+// Shard d > 0 of a render at the resolution of shard 0: its own State on GPU (first device + d) modulo the number
+// of GPUs -- with fewer GPUs than shards several shards share one, which changes the speed and nothing else.
+State& ensure_shard(int d, const State& first) {
+  int ndev = 1;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  if ((int)g_shards.size() < d) g_shards.resize((size_t)d, nullptr);
+  State*& sh = g_shards[(size_t)d - 1];
+  const int device = (first.device + d) % std::max(ndev, 1);
+  if (sh && (sh->width != first.width || sh->height != first.height || sh->device != device)) {
+    delete sh;
+    sh = nullptr;
+  }
+  if (!sh) {
+    sh = make_state(first.width, first.height, device);
+    sh->quiet = true;
+    int can = 0;  // direct copies over xGMI where the GPUs allow it; the copy works either way
+    if (device != first.device && hipDeviceCanAccessPeer(&can, first.device, device) == hipSuccess && can) {
+      HIP_CHECK(hipSetDevice(first.device));
+      (void)hipDeviceEnablePeerAccess(device, 0);
+      (void)hipGetLastError();
+    }
+  }
+  HIP_CHECK(hipSetDevice(sh->device));
+  if (sh->scene_version != g_scene_version) upload_scene(*sh);
+  if (sh->guide_version != g_snap_version) upload_guide(*sh);
+  sh->cam = first.cam;
+  sh->bayer_pattern = first.bayer_pattern;
+  return *sh;
+}
+
+// One render call split by sample index over n shards, one host thread and one GPU each (optix_wrapper.cpp:1102-1115
+// stays the only call the host makes): shard d renders samples [d*spp/n, (d+1)*spp/n) of every pixel exactly as
+// rank d of a multi-process render would, the shards' per-pixel totals are copied to shard 0's GPU and added there in
+// shard order, and shard 0 divides by the number of samples taken.  Adaptive renders stop each shard's pixels on the
+// shard's own statistics.
+void render_mean_sharded(State& s, int n, int spp, int max_depth, float noise_threshold, int min_adaptive_samples) {
+  const uint32_t npx = (uint32_t)((size_t)s.width * (size_t)s.height);
+  (void)current_bvh();  // built once, before the threads need it
+  std::vector<State*> st((size_t)n);
+  st[0] = &s;
+  for (int d = 1; d < n; ++d) st[(size_t)d] = &ensure_shard(d, s);
+  for (State* sd : st) {
+    HIP_CHECK(hipSetDevice(sd->device));
+    if (!sd->d_sum4) sd->d_sum4 = dev_alloc<q4>(npx);
+    if (noise_threshold > 0.0f) ensure_adaptive(*sd);
+  }
+  HIP_CHECK(hipSetDevice(s.device));
+  if (s.peer_capacity < (size_t)(n - 1) * npx) {
+    dev_free(s.d_peer);
+    s.peer_capacity = (size_t)(n - 1) * npx;
+    s.d_peer = dev_alloc<q4>(s.peer_capacity);
+  }
+  const int frame = g_frame;
+  auto work = [&](int d) {
+    State& sd = *st[(size_t)d];
+    HIP_CHECK(hipSetDevice(sd.device));
+    const int begin = (int)((long long)d * spp / n), count = (int)((long long)(d + 1) * spp / n) - begin;
+    if (noise_threshold > 0.0f && count > 0)
+      render_adaptive(sd, begin, count, max_depth, frame, false, noise_threshold, min_adaptive_samples, nullptr);
+    else
+      render_core(sd, begin, count, max_depth, frame, false);
+    launch_shard_sums(sd.acc, sd.started, sd.d_sum4, npx, sd.last_chunks, sd.stream);
+    HIP_CHECK(hipStreamSynchronize(sd.stream));
+  };
+  std::vector<std::thread> threads;
+  for (int d = 1; d < n; ++d) threads.emplace_back(work, d);
+  work(0);
+  for (std::thread& t : threads) t.join();
+  HIP_CHECK(hipSetDevice(s.device));
+  for (int d = 1; d < n; ++d)
+    HIP_CHECK(hipMemcpyPeerAsync(s.d_peer + (size_t)(d - 1) * npx, s.device, st[(size_t)d]->d_sum4, st[(size_t)d]->device,
+                                 (size_t)npx * sizeof(q4), s.stream));
+  launch_reduce_shards(s.d_sum4, s.d_peer, n - 1, s.d_out_rgb, npx, s.stream);
+}
+
 int render_mean(State& s, int spp, int max_depth, float noise_threshold, int min_adaptive_samples) {
   g_frame++;  // optix_wrapper.cpp:983
   const bool strict = mode() == PT_MODE_STRICT;
+  // strict mode replays the reference's launches one pixel stream at a time: never sharded
+  const int shards = strict ? 1 : std::min(shard_setting(), std::max(spp, 1));
+  if (shards > 1) {
+    render_mean_sharded(s, shards, spp, max_depth, noise_threshold, min_adaptive_samples);
+    return 0;
+  }
   if (noise_threshold > 0.0f && spp > 0)
     render_adaptive(s, 0, spp, max_depth, g_frame, strict, noise_threshold, min_adaptive_samples);
   else
@@ -761,7 +864,7 @@ State::~State() {
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);
   dev_free(shared_acc); dev_free(shared_acc2); dev_free(shared_n);
-  dev_free(d_out_rgb); dev_free(d_out_bayer);
+  dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_sum4); dev_free(d_peer);
   dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid);
   if (h_counters) (void)hipHostFree(h_counters);
   for (int i = 0; i < 2; ++i) if (ev_slot[i]) (void)hipEventDestroy(ev_slot[i]);
@@ -813,12 +916,17 @@ void optix_synchronize(void) {
     HIP_CHECK(hipStreamSynchronize(g_handle->stream));
     HIP_CHECK(hipStreamSynchronize(g_handle->copy_stream));
   }
+  for (State* sh : g_shards)
+    if (sh) HIP_CHECK(hipStreamSynchronize(sh->stream));
 }
 
 void* optix_ctx_create(int width, int height) { return make_state(width, height); }
 void optix_ctx_destroy(void* handle) {
   State* s = static_cast<State*>(handle);
-  if (s == g_handle) g_handle = nullptr;
+  if (s == g_handle) {
+    g_handle = nullptr;
+    drop_shards();
+  }
   delete s;
 }
 void optix_ctx_set_bayer(void* handle, int pattern) { static_cast<State*>(handle)->bayer_pattern = pattern; }
@@ -849,34 +957,49 @@ void guiding_map_train_samples(const TrainSample** samples, uint32_t* count) {
   if (samples) *samples = nullptr;
   if (count) *count = 0;
   if (!g_handle) return;
-  State& st = *g_handle;
-  if (!st.d_train || !st.d_train_idx || st.train_capacity == 0) return;
-  HIP_CHECK(hipSetDevice(st.device));
-  host.resize(st.train_capacity);
   static_assert(sizeof(TrainSample) == sizeof(TrainRec), "layout");
-  HIP_CHECK(hipMemcpy(host.data(), st.d_train, sizeof(TrainSample) * (size_t)st.train_capacity, hipMemcpyDeviceToHost));
-  uint32_t n = 0;
-  HIP_CHECK(hipMemcpy(&n, st.d_train_idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
-  // vertices land in hashed slots (see capture_train): keep the slots that were written, in ring order
-  size_t kept = 0;
-  for (size_t i = 0; i < host.size(); ++i) {
-    if (host[i].is_delta == kTrainEmpty) continue;
-    TrainRec rec;
-    memcpy(&rec, &host[i], sizeof(rec));
-    if ((rec.is_delta & ~1u) != train_digest(rec)) continue;  // two vertices were written here at once
-    host[i].is_delta &= 1u;
-    host[kept++] = host[i];
+  // one ring per sample shard (pt_set_device_count): the records of all of them, shard 0 first
+  std::vector<State*> states{g_handle};
+  for (State* sh : g_shards)
+    if (sh) states.push_back(sh);
+  host.clear();
+  std::vector<TrainSample> ring;
+  for (State* stp : states) {
+    State& st = *stp;
+    if (!st.d_train || !st.d_train_idx || st.train_capacity == 0) continue;
+    HIP_CHECK(hipSetDevice(st.device));
+    ring.resize(st.train_capacity);
+    HIP_CHECK(hipMemcpy(ring.data(), st.d_train, sizeof(TrainSample) * (size_t)st.train_capacity, hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    HIP_CHECK(hipMemcpy(&n, st.d_train_idx, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // vertices land in hashed slots (see capture_train): keep the slots that were written, in ring order;
+    // never more than were captured or than the ring holds (the reference reports the raw counter)
+    const size_t limit = host.size() + std::min(n, st.train_capacity);
+    for (size_t i = 0; i < ring.size() && host.size() < limit; ++i) {
+      if (ring[i].is_delta == kTrainEmpty) continue;
+      TrainRec rec;
+      memcpy(&rec, &ring[i], sizeof(rec));
+      if ((rec.is_delta & ~1u) != train_digest(rec)) continue;  // two vertices were written here at once
+      ring[i].is_delta &= 1u;
+      host.push_back(ring[i]);
+    }
   }
+  HIP_CHECK(hipSetDevice(g_handle->device));
   if (samples) *samples = host.data();
-  // never report more than were captured or than the ring holds (the reference reports the raw counter)
-  if (count) *count = (uint32_t)std::min<size_t>(kept, std::min(n, st.train_capacity));
+  if (count) *count = (uint32_t)host.size();
 }
 void guiding_reset_train_write_idx(void) {
-  if (!g_handle || !g_handle->d_train_idx) return;
+  if (!g_handle) return;
+  std::vector<State*> states{g_handle};
+  for (State* sh : g_shards)
+    if (sh) states.push_back(sh);
+  for (State* st : states) {
+    if (!st->d_train_idx) continue;
+    HIP_CHECK(hipSetDevice(st->device));
+    HIP_CHECK(hipMemset(st->d_train_idx, 0, sizeof(uint32_t)));
+    if (st->d_train) HIP_CHECK(hipMemset(st->d_train, 0xff, sizeof(TrainRec) * (size_t)st->train_capacity));
+  }
   HIP_CHECK(hipSetDevice(g_handle->device));
-  HIP_CHECK(hipMemset(g_handle->d_train_idx, 0, sizeof(uint32_t)));
-  if (g_handle->d_train)
-    HIP_CHECK(hipMemset(g_handle->d_train, 0xff, sizeof(TrainRec) * (size_t)g_handle->train_capacity));
 }
 
 // ======================================================================== Part 2
@@ -890,8 +1013,23 @@ void pt_set_device(int d) {
   if (d != device_index()) {
     delete g_handle;
     g_handle = nullptr;
+    drop_shards();
   }
   g_device = d;
+}
+void pt_set_device_count(int n) {
+  g_gpus = n > 0 ? n : 1;
+  if ((int)g_shards.size() > g_gpus - 1) {  // shards no longer used give their memory back
+    for (size_t d = (size_t)g_gpus - 1; d < g_shards.size(); ++d) delete g_shards[d];
+    g_shards.resize((size_t)g_gpus - 1);
+  }
+}
+int pt_get_device_count(void) { return shard_setting(); }
+void pt_shard_range(int spp, int n_shards, int shard, int* begin, int* count) {
+  const int n = n_shards > 0 ? n_shards : 1, d = std::min(std::max(shard, 0), n - 1);
+  const int b = (int)((long long)d * spp / n), e = (int)((long long)(d + 1) * spp / n);
+  if (begin) *begin = b;
+  if (count) *count = e - b;
 }
 void pt_set_frame(int frame) {
   g_frame = frame;

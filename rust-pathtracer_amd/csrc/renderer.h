@@ -74,6 +74,13 @@ struct State {
   q4 *shared_acc = nullptr, *shared_acc2 = nullptr;  // statistics summed over ranks (shared noise test)
   int* shared_n = nullptr;
 
+  // sample shards rendered side by side in one process (pt_set_device_count): this shard's totals, on shard 0 the
+  // landing area for the other shards' totals; a shard other than 0 keeps out of the global statistics
+  q4* d_sum4 = nullptr;
+  q4* d_peer = nullptr;
+  size_t peer_capacity = 0;  // q4 elements
+  bool quiet = false;
+
   // outputs
   float* d_out_rgb = nullptr;
   float* d_out_bayer = nullptr;

@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
     else if (arg_value(a, "--noise-threshold", v)) noise_threshold = (float)atof(v.c_str());
     else if (arg_value(a, "--min-adaptive", v)) min_adaptive_samples = atoi(v.c_str());
     else if (arg_value(a, "--pattern", v)) pattern = atoi(v.c_str());
+    else if (arg_value(a, "--gpus", v)) pt_set_device_count(atoi(v.c_str()));  // sample shards, one GPU each
     else if (arg_value(a, "--demosaic", v)) fast_demosaic = (v == "bilinear");
     else if (arg_value(a, "--mode", v)) pt_set_mode(v == "strict" ? PT_MODE_STRICT : PT_MODE_CONVERGE);
     else if (arg_value(a, "--pipeline", v)) pt_set_pipeline(v == "staged" ? PT_PIPELINE_STAGED : PT_PIPELINE_FUSED);

@@ -80,6 +80,9 @@ SIGNATURES = {
     "pt_set_pipeline": (None, [C.c_int]),
     "pt_get_pipeline": (C.c_int, []),
     "pt_set_device": (None, [C.c_int]),
+    "pt_set_device_count": (None, [C.c_int]),
+    "pt_get_device_count": (C.c_int, []),
+    "pt_shard_range": (None, [C.c_int, C.c_int, C.c_int, _ip, _ip]),
     "pt_set_frame": (None, [C.c_int]),
     "pt_get_frame": (C.c_int, []),
     "pt_render_accumulate_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -118,6 +118,11 @@ class ShardedGuiding:
         self.many = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.rank = dist.get_rank(group) if self.many else 0
         self.world = dist.get_world_size(group) if self.many else 1
+        # RCCL ("nccl") moves device tensors only: the records and the snapshot then pass through this rank's GPU;
+        # gloo takes them from host memory as they are
+        self.cdev = torch.device("cpu")
+        if self.many and dist.get_backend(group) == "nccl":
+            self.cdev = torch.device("cuda", torch.cuda.current_device())
         self.field = pt.GuidingField(scene_min, scene_max) if self.rank == 0 else None
         self.collect = collect or pt.train_samples
         self.upload = upload or pt.upload_snapshot
@@ -126,29 +131,32 @@ class ShardedGuiding:
     def process_batch(self):
         """One update: gather, train on rank 0, broadcast, upload.  Returns (regions, lobes), the same on all ranks."""
         local = torch.from_numpy(self.collect().astype("float32", copy=False).reshape(-1, 10).copy())
+        dev = self.cdev
         if self.many:
-            sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
-            dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64), group=self.group)
-            longest = max(int(x) for x in sizes)
-            padded = torch.zeros((longest, 10), dtype=torch.float32)
-            padded[: local.shape[0]] = local
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+            dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=dev), group=self.group)
+            sizes = [int(x) for x in sizes]
+            longest = max(sizes)
+            padded = torch.zeros((longest, 10), dtype=torch.float32, device=dev)
+            padded[: local.shape[0]] = local.to(dev)
             parts = [torch.zeros_like(padded) for _ in range(self.world)] if self.rank == 0 else None
             dist.gather(padded, parts, dst=0, group=self.group)
             if self.rank == 0:
-                local = torch.cat([p[: int(n)] for p, n in zip(parts, sizes)])
+                local = torch.cat([p[:n] for p, n in zip(parts, sizes)]).cpu()
         if self.rank == 0:
             self.field.update(local.numpy())
             regions, lobes = self.field.snapshot()
-            shape = torch.tensor([regions.shape[0], lobes.shape[0]], dtype=torch.int64)
+            shape = torch.tensor([regions.shape[0], lobes.shape[0]], dtype=torch.int64, device=dev)
         else:
-            shape = torch.zeros(2, dtype=torch.int64)
+            shape = torch.zeros(2, dtype=torch.int64, device=dev)
         if self.many:
             dist.broadcast(shape, src=0, group=self.group)
-            r = torch.from_numpy(regions) if self.rank == 0 else torch.zeros((int(shape[0]), 8), dtype=torch.float32)
-            l = torch.from_numpy(lobes) if self.rank == 0 else torch.zeros((int(shape[1]), 8), dtype=torch.float32)
+            nr, nl = int(shape[0]), int(shape[1])
+            r = torch.from_numpy(regions).to(dev) if self.rank == 0 else torch.zeros((nr, 8), dtype=torch.float32, device=dev)
+            l = torch.from_numpy(lobes).to(dev) if self.rank == 0 else torch.zeros((nl, 8), dtype=torch.float32, device=dev)
             dist.broadcast(r, src=0, group=self.group)
             dist.broadcast(l, src=0, group=self.group)
-            regions, lobes = r.numpy(), l.numpy()
+            regions, lobes = r.cpu().numpy(), l.cpu().numpy()
         self.upload(regions, lobes)
         self.reset()
         return regions, lobes

@@ -71,6 +71,7 @@ def gpu(pt):
     L.guiding_set_enabled(0)
     L.pt_set_mode(pt.MODE_CONVERGE)
     L.pt_set_pipeline(pt.PIPELINE_FUSED)
+    L.pt_set_device_count(1)
     L.pt_set_frame(0)
     L.pt_reset_ray_counts()
     return pt

@@ -645,6 +645,56 @@ def test_sample_chunks_sum_like_ranks(gpu):
     assert r[0, 0] == pytest.approx(max(both[0, 0, 2] / 16, 0), rel=1e-6)  # BGGR: (0,0) is blue
 
 
+def test_in_library_shards_equal_the_ranks_they_stand_for(gpu):
+    """pt_set_device_count(n): the reference's own entry point renders n sample shards side by side (here all
+    on one GPU) and adds them in shard order.  The image is, bit for bit, what n ranks produce through
+    pt_render_accumulate_device with the same sample ranges, summed in rank order and divided by the count;
+    the mosaic entry point and the ray totals follow; one shard is the plain render."""
+    import torch
+    L = gpu.lib()
+    w, h, spp, n = 96, 54, 100, 3
+    dev = torch.device("cuda:0")
+    try:
+        L.pt_set_device_count(n)
+        L.pt_set_frame(4)
+        L.pt_reset_ray_counts()
+        img = gpu.render_rgb(w, h, spp)  # frame 5
+        rays_sharded = gpu.ray_counts()
+        L.pt_set_frame(4)
+        raw = gpu.render_bayer(w, h, spp, pattern=2)
+        L.pt_set_device_count(1)
+        total = None
+        L.pt_reset_ray_counts()
+        for d in range(n):
+            b, c = C.c_int(), C.c_int()
+            L.pt_shard_range(spp, n, d, C.byref(b), C.byref(c))
+            part = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            gpu.render_accumulate_device(part, w, h, b.value, c.value, 32, 5)
+            part = part.cpu().numpy()
+            total = part if total is None else total + part
+        assert gpu.ray_counts() == rays_sharded
+        expect = (total * (np.float32(1.0) / np.float32(spp))).reshape(h, w, 3)
+        assert np.array_equal(img.view(np.uint32), expect.view(np.uint32))
+        ys, xs = np.mgrid[0:h, 0:w]
+        ch = np.where(ys % 2 == 0, np.where(xs % 2 == 0, 1, 0), np.where(xs % 2 == 0, 2, 1))  # GRBG
+        assert np.array_equal(raw, np.maximum(np.take_along_axis(expect, ch[..., None], axis=2)[..., 0], 0))
+        # one shard: the plain render; more shards than samples: one sample each
+        L.pt_set_frame(4)
+        plain = gpu.render_rgb(w, h, spp)
+        L.pt_set_device_count(8)
+        L.pt_set_frame(4)
+        few = gpu.render_rgb(w, h, 3)
+        assert np.isfinite(few).all() and abs(few.mean() - plain.mean()) / plain.mean() < 0.2
+        # adaptive renders shard too (each shard stops pixels on its own statistics)
+        L.pt_set_device_count(2)
+        L.pt_set_frame(4)
+        ada = gpu.render_rgb(w, h, 256, noise_threshold=0.5, min_adaptive_samples=32)
+        assert np.isfinite(ada).all() and abs(ada.mean() - plain.mean()) / plain.mean() < 0.05
+    finally:
+        L.pt_set_device_count(1)
+
+
 def test_boundary_utilities(gpu):
     """Pinned host buffers (optix_wrapper.cpp:1132-1164), synchronize, the explicit context API
     (927-976) and the four Bayer patterns (optix_device.cu:902-912)."""

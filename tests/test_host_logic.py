@@ -515,6 +515,28 @@ def test_scene_triangles_checks_its_input(pt):
     L.pt_scene_cornell()
 
 
+def test_shard_ranges_partition_the_samples(pt):
+    """pt_shard_range: the in-library shards of a render call are contiguous, disjoint, cover [0, spp) and differ
+    by at most one sample; the setting itself needs no GPU."""
+    L = pt.lib()
+    for spp in (0, 1, 5, 64, 1000, 1024, 4097):
+        for n in (1, 2, 3, 4, 8, 16):
+            pos, sizes = 0, []
+            for d in range(n):
+                b, c = C.c_int(), C.c_int()
+                L.pt_shard_range(spp, n, d, C.byref(b), C.byref(c))
+                assert b.value == pos and c.value >= 0
+                pos += c.value
+                sizes.append(c.value)
+            assert pos == spp and max(sizes) - min(sizes) <= 1
+    before = L.pt_get_device_count()
+    L.pt_set_device_count(4)
+    assert L.pt_get_device_count() == 4
+    L.pt_set_device_count(0)
+    assert L.pt_get_device_count() == 1
+    L.pt_set_device_count(before)
+
+
 def test_pgl_stand_in_trainer(pt):
     """ABI and ownership of the pgl_* calls (openpgl_bridge.h:7-33); the trainer itself is not OpenPGL."""
     L = pt.lib()
