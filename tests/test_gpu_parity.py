@@ -329,6 +329,96 @@ def test_shade_step_matches_oracle(gpu, oracle):
     assert frac > 0.99, frac
 
 
+@pytest.mark.parametrize("case", [0, 1])
+def test_shade_step_means_match_quadrature(gpu, oracle, case):
+    """The GPU shading step against mathematics, not against the oracle: 400 000 random states at a floor
+    point; mean next-event contribution, mean throughput factor and mean total contribution against the
+    float64 quadrature of optix_device.cu:484-658 in tests/math_pins.py, within 4.5 standard errors."""
+    import math_pins as mp
+    from test_oracle_golden import FLOOR_CASES, floor_case
+    eye, point = FLOOR_CASES[case]
+    hit, eye32, d32, n, v = floor_case(oracle, eye, point)  # the oracle only looks the primitive up
+    e_lo = mp.expected_nee(np.array(point, np.float64), n, v)
+    e_w, _ = mp.expected_throughput_factor(n, v)
+    t0 = np.array([0.9, 0.7, 0.5])
+    N = 400000
+    recs = (HcRec * N)()
+    rng = np.random.default_rng(12)
+    seeds = rng.integers(0, 2 ** 63, N, dtype=np.uint64)
+    for i in range(N):
+        r = recs[i]
+        r.throughput[:] = t0.tolist()
+        r.origin[:] = eye32.tolist()
+        r.direction[:] = d32.tolist()
+        r.seed = int(seeds[i])
+        r.rng_dim = 2
+    prims = np.full(N, hit.prim, np.int32)
+    b1 = np.full(N, hit.b1, np.float32)
+    b2 = np.full(N, hit.b2, np.float32)
+    out, shadow = _gpu_shade(gpu)(recs, prims, b1, b2)
+    assert shadow.all()
+    arr = np.frombuffer(out, dtype=np.uint8).reshape(N, C.sizeof(HcRec))
+    f = arr[:, :48].copy().view(np.float32).reshape(N, 12).astype(np.float64)
+    contrib, thr = f[:, 0:3], f[:, 3:6]  # the radiance slot returns radiance * throughput
+    for name, samples, expect in (("throughput", thr, t0 * e_w), ("contribution", contrib, e_lo * t0 * e_w)):
+        mean, sem = samples.mean(0), samples.std(0) / np.sqrt(N)
+        assert (np.abs(mean - expect) < 4.5 * sem + 2e-4 * expect).all(), (name, mean, expect, sem)
+        assert (sem < 0.03 * expect).all()
+    # the next-event term alone: contribution / throughput, where the throughput is not tiny
+    ok = thr.min(1) > 1e-3
+    lo = contrib[ok] / thr[ok]
+    mean, sem = lo.mean(0), lo.std(0) / np.sqrt(ok.sum())
+    assert ok.mean() > 0.99 and (np.abs(mean - e_lo) < 4.5 * sem + 2e-3 * e_lo).all(), (mean, e_lo, sem)
+
+
+def test_vmf_samples_on_the_gpu_follow_their_density(gpu):
+    """vmf_sample on the device (through pt_dbg_guiding, one region, one lobe) against the analytic von
+    Mises-Fisher cdf and a uniform azimuth, chi-square, for a broad, a medium and a sharp lobe; the mixture pdf
+    of a single lobe against kappa / (4 pi sinh kappa) exp(kappa mu . omega)."""
+    import math_pins as mp
+    L = gpu.lib()
+    rng = np.random.default_rng(8)
+    mu = np.array([0.36, -0.48, 0.8])
+    t1 = np.cross(mu, [0, 0, 1.0]); t1 /= np.linalg.norm(t1)
+    t2 = np.cross(mu, t1)
+    n_s = 200000
+    try:
+        for kappa in (0.5, 8.0, 60.0):
+            regions = np.array([[-1, -1, 0, 1, 1, 2, 0, 1]], np.float32)
+            lobes = np.array([[mu[0], mu[1], mu[2], kappa, 1.0, 1, 1, 1]], np.float32)
+            L.guiding_set_grid_res(1, 1, 1)
+            gpu.upload_snapshot(regions, lobes)
+            pos = np.tile(np.array([[0.1, 0.2, 0.7]], np.float32), (n_s, 1))
+            u3 = rng.random((n_s, 3)).astype(np.float32)
+            wi = rng.normal(size=(n_s, 3)).astype(np.float32)
+            wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+            reg, lobe = np.zeros(n_s, np.int32), np.zeros(n_s, np.int32)
+            dirs = np.zeros((n_s, 3), np.float32)
+            pd, pw = np.zeros(n_s, np.float32), np.zeros(n_s, np.float32)
+            assert L.pt_dbg_guiding(n_s, P(pos), P(u3), P(wi), P(reg, C.c_int), P(lobe, C.c_int), P(dirs), P(pd), P(pw)) == 0
+            assert (reg == 0).all() and (lobe == 0).all()
+            w = dirs.astype(np.float64)
+            assert np.allclose(np.linalg.norm(w, axis=1), 1.0, atol=1e-4)
+            cdf = mp.vmf_cdf(w @ mu, kappa)
+            phi = np.mod(np.arctan2(w @ t2, w @ t1), 2 * np.pi) / (2 * np.pi)
+            for values, bins in ((cdf, 20), (phi, 12)):
+                counts = np.histogram(values, bins=np.linspace(0, 1, bins + 1))[0]
+                chi2 = ((counts - n_s / bins) ** 2 / (n_s / bins)).sum()
+                assert chi2 < mp.chi2_threshold(bins - 1), (kappa, bins, chi2)
+            exact = kappa / (2 * np.pi * (1 - np.exp(-2 * kappa))) * np.exp(kappa * (wi.astype(np.float64) @ mu - 1))
+            assert np.allclose(pw, exact, rtol=2e-3, atol=1e-7)
+    finally:
+        L.guiding_set_enabled(0)
+
+
+def test_depth_one_render_matches_quadrature(gpu):
+    """The GPU's whole render path at max_depth = 1 against the same quadrature the oracle is pinned with."""
+    from test_oracle_golden import DEPTH_ONE, check_depth_one_block
+    gpu.lib().pt_set_frame(2)
+    img = gpu.render_rgb(DEPTH_ONE["width"], DEPTH_ONE["height"], DEPTH_ONE["spp"], max_depth=1)
+    check_depth_one_block(img)
+
+
 def test_shade_miss_terminates(gpu):
     n = 8
     recs = (HcRec * n)()
