@@ -779,6 +779,30 @@ void orc_closesthit(orc_prd* prd, const orc_hit* hit, int frame, int max_depth,
   closesthit(prd, hit, &c);
 }
 
+/* Test instrumentation, no counterpart in the reference: marks the pixels one of whose rays starts (to
+ * within 1e-5) IN the plane of some triangle.  The reference pushes every new origin 1e-3 off the surface it
+ * leaves (optix_device.cu:455-466, 577, 640), which puts a path that leaves the glass box through its bottom
+ * face (z = 0.001) exactly on the floor; whether such a ray sees that plane is rounding noise in any
+ * implementation, and tests use the marks to tell these pixels from real disagreements. */
+static unsigned char* g_on_plane_flags = NULL;
+void orc_set_on_plane_flags(unsigned char* per_pixel) { g_on_plane_flags = per_pixel; }
+static int origin_on_a_plane(const float o[3]) {
+  for (int t = 0; t < g_ntri; ++t) {
+    const f3 n = normalize3(ld3(g_normals + 3 * t));
+    const f3 v0 = ld3(g_vertices + 3 * g_indices[3 * t]);
+    const f3 rel = sub3(ld3(o), v0);
+    if (fabsf(dot3(n, rel)) >= 1e-5f) continue;
+    /* in the plane: also (nearly) inside the triangle?  barycentrics from the dual basis of the edges */
+    const f3 e1 = sub3(ld3(g_vertices + 3 * g_indices[3 * t + 1]), v0), e2 = sub3(ld3(g_vertices + 3 * g_indices[3 * t + 2]), v0);
+    const float d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), r1 = dot3(rel, e1), r2 = dot3(rel, e2);
+    const float det = d11 * d22 - d12 * d12;
+    if (!(det > 0.0f)) continue;
+    const float b1 = (d22 * r1 - d12 * r2) / det, b2 = (d11 * r2 - d12 * r1) / det;
+    if (b1 >= -0.01f && b2 >= -0.01f && b1 + b2 <= 1.01f) return 1;
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ raygen */
 typedef struct {
   const orc_render_args* a;
@@ -863,6 +887,7 @@ static void raygen(launch_ctx* L, uint32_t dst, uint64_t rays[2]) {
     while (!prd.done) {
       prd.radiance[0] = prd.radiance[1] = prd.radiance[2] = 0.0f;
       rays[0]++;
+      if (g_on_plane_flags && origin_on_a_plane(prd.origin)) g_on_plane_flags[dst] = 1;
       orc_hit hit = orc_trace_closest(prd.origin, prd.direction, 0.0f, 1e16f);
       if (hit.prim < 0) {
         prd.radiance[0] = prd.radiance[1] = prd.radiance[2] = 0.0f;

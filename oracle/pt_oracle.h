@@ -155,6 +155,10 @@ void  orc_guiding_build_grid(const orc_region* regions, uint32_t n_regions, cons
 /* ---- full render (optix_device.cu:914-1071 driven by optix_wrapper.cpp:978-1027) ----
  * out_rgb: w*h*3, out_bayer: w*h, sample_counts: w*h (may be NULL),
  * ray_counts[2]: radiance rays, shadow rays (may be NULL). */
+/* Test instrumentation (no counterpart in the reference): while set, orc_render marks per_pixel[y * width + x] = 1
+ * for every pixel one of whose radiance rays starts within 1e-5 of the plane of some triangle (the reference's
+ * 1e-3 origin offset puts a path that leaves the glass box through its bottom face exactly on the floor). */
+void orc_set_on_plane_flags(unsigned char* per_pixel);
 int orc_render(const orc_render_args* a, float* out_rgb, float* out_bayer,
                int* sample_counts, uint64_t ray_counts[2]);
 

@@ -129,6 +129,7 @@ def lib():
     L.orc_guiding_build_grid.argtypes = [C.POINTER(Region), C.c_uint32, ip, u32p, ip, fp, fp, fp]
     L.orc_render.restype = C.c_int
     L.orc_render.argtypes = [C.POINTER(RenderArgs), fp, fp, ip, C.POINTER(C.c_uint64)]
+    L.orc_set_on_plane_flags.argtypes = [C.c_void_p]
     L.orc_cfa_at.restype = C.c_int
     L.orc_cfa_at.argtypes = [C.c_int] * 3
     L.orc_demosaic_amaze.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]
@@ -178,20 +179,39 @@ def make_guide(regions, lobes, grid_res):
 
 
 def render(width, height, spp, max_depth=32, frame=1, pattern=0, noise_threshold=0.0, min_adaptive=32,
-           mode=CONVERGE, sample_begin=0, adaptive_deterministic=0, nthreads=0, guide=None, adaptive_round=0):
-    """Returns (rgb[h,w,3], bayer[h,w], counts[h,w], (radiance_rays, shadow_rays))."""
+           mode=CONVERGE, sample_begin=0, adaptive_deterministic=0, nthreads=0, guide=None, adaptive_round=0,
+           train=None, on_plane=None):
+    """Returns (rgb[h,w,3], bayer[h,w], counts[h,w], (radiance_rays, shadow_rays)).
+    on_plane: a list; appends a uint8 [h,w] map of the pixels one of whose rays started in the plane of a triangle.
+    train: a list; the render then runs on one thread with a training buffer (optix_device.cu:431-441) and
+    appends one (n, 9) float32 array -- position, dir_in, contrib of every captured vertex, in capture order."""
     L = lib()
     if nthreads <= 0:
         nthreads = os.cpu_count() or 1
+    tbuf, tidx, tcap = None, None, 0
+    if train is not None:
+        tcap = 1 << 20
+        tbuf = (TrainSample * tcap)()
+        tidx = C.c_uint32(0)
     a = RenderArgs(width, height, spp, max_depth, frame, pattern, noise_threshold, min_adaptive, mode,
                    sample_begin, adaptive_deterministic, nthreads, adaptive_round,
-                   C.pointer(guide) if guide is not None else None, None, 0, None)
+                   C.pointer(guide) if guide is not None else None, tbuf, tcap, C.pointer(tidx) if tidx is not None else None)
     rgb = np.zeros((height, width, 3), np.float32)
     bayer = np.zeros((height, width), np.float32)
     counts = np.zeros((height, width), np.int32)
     rays = (C.c_uint64 * 2)()
+    if on_plane is not None:
+        flags = np.zeros((height, width), np.uint8)
+        L.orc_set_on_plane_flags(flags.ctypes.data_as(C.c_void_p))
     rc = L.orc_render(C.byref(a), fptr(rgb), fptr(bayer), counts.ctypes.data_as(C.POINTER(C.c_int)), rays)
+    if on_plane is not None:
+        L.orc_set_on_plane_flags(None)
+        on_plane.append(flags)
     assert rc == 0
+    if train is not None:
+        assert tidx.value <= tcap, "more vertices than the test buffer holds"
+        rec = np.frombuffer(tbuf, dtype=np.float32).reshape(tcap, 10)[: tidx.value, :9].copy()
+        train.append(rec)
     return rgb, bayer, counts, (int(rays[0]), int(rays[1]))
 
 

@@ -56,13 +56,35 @@ def test_blue_noise_and_jitter(gpu, oracle):
         OL.orc_blue_noise(int(q[i, 0]), int(q[i, 1]), int(q[i, 2]), int(q[i, 3]), a)
         OL.orc_olpf_jitter(int(q[i, 0]), int(q[i, 1]), int(q[i, 2]), int(q[i, 3]), b)
         wuv[i], wjit[i] = list(a), list(b)
-    # the hash is integer-exact; the R2 offset rx + (s+0.5)*c may contract into an FMA on the GPU:
-    # one rounding of a value below 4096 is 2.4e-4 at most, typically 0 -- measured on the circle,
-    # since fract() of a value next to an integer may land on either side
+    # What the device computes, exactly: the hash is integer arithmetic; u = fract(rx + (s + 0.5) * c) with the
+    # product and the sum fused into one FMA (one rounding instead of the oracle's two).  Modelled in float64
+    # (the sum of a 16-bit and a 48-bit number is exact there, so rounding it to float32 IS the FMA).
+    def hash_u32(x):
+        x = np.uint64(x)
+        m = np.uint64(0xffffffff)
+        for shift, mul in ((17, 0xed5ad4bb), (11, 0xac4c1b51), (15, 0x31848bab)):
+            x ^= x >> np.uint64(shift)
+            x = (x * np.uint64(mul)) & m
+        return x ^ (x >> np.uint64(14))
+    hv = np.array([int(hash_u32((int(x) * 1973 + int(y) * 9277 + int(f) * 26699) & 0xffffffff)) for x, y, _, f in q])
+    r = np.stack([(hv & 0xffff) / 65536.0, (hv >> 16) / 65536.0], 1)
+    c32 = np.array([np.float32(1.0) / np.float32(1.32471795724474602596),
+                    np.float32(1.0) / (np.float32(1.32471795724474602596) * np.float32(1.32471795724474602596))], np.float32)
+    fs = (q[:, 2].astype(np.float32) + np.float32(0.5)).astype(np.float64)
+    fused = (r + fs[:, None] * c32.astype(np.float64)[None, :]).astype(np.float32)
+    model = fused - np.floor(fused)
+    assert np.array_equal(uv, model)  # bit for bit, all 8192 values
+    # against the oracle (product rounded, then sum rounded): equal except where that extra rounding shows;
+    # measured on the circle, since fract() of a value next to an integer may land on either side
     duv = np.abs(uv - wuv)
     duv = np.minimum(duv, 1.0 - duv)
-    assert duv.max() < 5e-4
-    assert np.mean(uv == wuv) > 0.5
+    assert duv.max() < 5e-4  # one rounding of a value below 4096
+    exact = np.mean(uv == wuv)
+    assert exact > 0.7, exact  # measured: 0.78 of the values are the oracle's bits
+    # jitter: sample_tri of the device's own u with a 1-ulp hardware square root
+    u64 = uv.astype(np.float64)
+    tri = np.where(u64 < 0.5, np.sqrt(2.0 * u64) - 1.0, 1.0 - np.sqrt(2.0 * (1.0 - u64)))
+    assert np.abs(jit - tri).max() < 2.5e-7
     same_side = (np.abs(uv - wuv) < 0.5).all(axis=1)
     crossing = (np.abs(uv - 0.5) < 1e-3).any(axis=1)  # sample_tri has a square-root kink at 0.5
     sel = same_side & ~crossing
@@ -615,6 +637,41 @@ def test_train_sample_ring(gpu):
         gpu.render_rgb(41, 30, 1)  # drop the renderer that owns the ring
 
 
+def test_train_capture_is_the_oracles_set_of_vertices(gpu, oracle):
+    """optix_device.cu:431-441 against the oracle, record by record.  The reference appends every non-delta
+    vertex {position, -direction, throughput on arrival}; the device stores the same records at hashed slots.
+    With a ring a thousand times larger than the number of vertices (no two share a slot) the mapped records must
+    be the oracle's set: same count up to the paths that part ways at a grazing edge, and nearly every oracle
+    record has a device twin within 1e-4."""
+    from scipy.spatial import cKDTree
+    L = gpu.lib()
+    w, h, spp = 16, 12, 4
+    got = []
+    oracle.render(w, h, spp, frame=1, mode=oracle.STRICT, train=got)
+    ref = got[0]
+    assert len(ref) > 1500
+    L.guiding_set_train_buffer_size(1 << 22)
+    try:
+        for pipeline in (0, 1):
+            L.pt_set_pipeline(pipeline)
+            L.pt_set_mode(gpu.MODE_STRICT)
+            L.pt_set_frame(0)
+            gpu.render_rgb(w, h, spp)  # new resolution -> renderer with the ring
+            rec = gpu.train_samples()
+            L.guiding_reset_train_write_idx()
+            assert (rec[:, 9].view(np.uint32) == 0).all()
+            assert abs(len(rec) - len(ref)) <= 0.03 * len(ref), (len(rec), len(ref))
+            dist, _ = cKDTree(rec[:, :9].astype(np.float64)).query(ref.astype(np.float64))
+            assert (dist < 1e-4).mean() > 0.9, (dist < 1e-4).mean()
+            back, _ = cKDTree(ref.astype(np.float64)).query(rec[:, :9].astype(np.float64))
+            assert (back < 1e-4).mean() > 0.9  # and the device invents none
+    finally:
+        L.pt_set_mode(gpu.MODE_CONVERGE)
+        L.pt_set_pipeline(1)
+        L.guiding_set_train_buffer_size(0)
+        gpu.render_rgb(17, 12, 1)  # drop the renderer that owns the ring
+
+
 # ------------------------------------------------------------------ a6 / a11 whole renders
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_strict_render_matches_golden(gpu, pipeline):
@@ -640,6 +697,31 @@ def test_strict_render_matches_golden(gpu, pipeline):
     ch = np.array([[(x & 1) + (y & 1) for x in range(32)] for y in range(32)])  # RGGB: 0 / 1 / 2
     want = np.maximum(np.take_along_axis(img, ch[..., None], 2)[..., 0], 0)
     assert np.array_equal(raw, want)
+
+
+def test_strict_mismatches_are_the_rays_that_start_on_a_plane(gpu, oracle):
+    """Why a strict-mode render is not the oracle's in every pixel.  The reference pushes a new origin 1e-3 off
+    the surface it leaves, which puts a path leaving the glass box through its bottom face (z = 0.001) exactly
+    on the floor; whether that ray sees the floor is the sign of a rounding error, different in any two
+    implementations.  The oracle marks the pixels where one of its rays starts in a triangle's plane: away from
+    them the device agrees in (nearly) every pixel, and the pixels that disagree are (nearly) all marked."""
+    L = gpu.lib()
+    w, h, spp = 96, 72, 4
+    marks = []
+    ref = oracle.render(w, h, spp, frame=1, mode=oracle.STRICT, on_plane=marks)[0]
+    marked = marks[0].astype(bool)
+    assert 0.01 < marked.mean() < 0.3
+    for pipeline in (0, 1):
+        L.pt_set_pipeline(pipeline)
+        L.pt_set_mode(gpu.MODE_STRICT)
+        L.pt_set_frame(0)
+        img = gpu.render_rgb(w, h, spp)
+        close = (np.abs(img - ref) <= 2e-3 + 2e-3 * np.abs(ref)).all(axis=2)
+        assert close[~marked].mean() > 0.985, close[~marked].mean()   # the rest: a grazing edge, a random number
+        assert marked[~close].mean() > 0.7, marked[~close].mean()     # on a probability (branch flips)
+        assert close[marked].mean() < close[~marked].mean()
+    L.pt_set_mode(gpu.MODE_CONVERGE)
+    L.pt_set_pipeline(1)
 
 
 def test_pipelines_agree_and_are_deterministic(gpu):
