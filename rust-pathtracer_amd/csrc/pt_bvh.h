@@ -482,6 +482,11 @@ struct TraceState {
     tg.bits &= tg.bits - 1u;
     const q4* tp = sc.tris + (uint32_t)kTriWords * (tg.base + (uint32_t)ti);
     const q4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+#if PT_ON_DEVICE
+    // The record comes from device memory here: all four words in one round trip.  Left alone, the compiler
+    // sinks the loads of the two barycentric rows behind the plane-distance test, a second dependent miss per item.
+    asm volatile("" ::"v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w));
+#endif
     int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, tmin, hit);
     if (res == 2) res = watertight_item(sc, q1, q2, q3, o, d, tmin, hit) ? 1 : 0;
     return res == 1 && any_hit;

@@ -140,6 +140,8 @@ def lib():
                 "There is no CPU fallback for the render path.")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if "PT_LIB_PATH" in os.environ and not hasattr(L, name):
+                continue  # an older build of the ABI under comparison
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
