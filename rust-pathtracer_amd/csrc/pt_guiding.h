@@ -1,15 +1,19 @@
 // pt_guiding.h -- path-guiding field lookup and von Mises-Fisher sampling (a13).
-// Restates optix/guiding_gpu.cuh:35-118 for the gfx950 shade stage.
+// The arithmetic of optix/guiding_gpu.cuh:35-118 for the gfx950 shade stage, on records that carry what the
+// reference recomputes at every query (pt_types.h: GuideLobeDev): one pass over a region's lobes picks the
+// lobe from running weight sums, one pass evaluates the mixture pdf with one exp2 per lobe.
 #pragma once
 #include "pt_types.h"
 
 namespace pt {
 
+PT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
 // guiding_gpu.cuh:35-45: uniform grid cell -> region id, -1 when the cell is empty
 PT_HD int guiding_region_id(const GuideView& G, f3 P) {
-  const float rx = (P.x - G.gmin[0]) / G.cell[0];
-  const float ry = (P.y - G.gmin[1]) / G.cell[1];
-  const float rz = (P.z - G.gmin[2]) / G.cell[2];
+  const float rx = (P.x - G.gmin[0]) * G.inv_cell[0];
+  const float ry = (P.y - G.gmin[1]) * G.inv_cell[1];
+  const float rz = (P.z - G.gmin[2]) * G.inv_cell[2];
   int cx = (int)rx, cy = (int)ry, cz = (int)rz;
   cx = cx > G.res[0] - 1 ? G.res[0] - 1 : cx; cx = cx < 0 ? 0 : cx;
   cy = cy > G.res[1] - 1 ? G.res[1] - 1 : cy; cy = cy < 0 ? 0 : cy;
@@ -18,18 +22,29 @@ PT_HD int guiding_region_id(const GuideView& G, f3 P) {
   return id == 0xFFFFFFFFu ? -1 : (int)id;
 }
 
-// guiding_gpu.cuh:60-78
-PT_HD f3 vmf_sample(f3 mu, float kappa, float ux, float uy) {
+// The same lookup returning the cell's region record itself (lobe_num == 0: no region or no lobes)
+PT_HD GuideRegionDev guiding_cell(const GuideView& G, f3 P) {
+  const float rx = (P.x - G.gmin[0]) * G.inv_cell[0];
+  const float ry = (P.y - G.gmin[1]) * G.inv_cell[1];
+  const float rz = (P.z - G.gmin[2]) * G.inv_cell[2];
+  int cx = (int)rx, cy = (int)ry, cz = (int)rz;
+  cx = cx > G.res[0] - 1 ? G.res[0] - 1 : cx; cx = cx < 0 ? 0 : cx;
+  cy = cy > G.res[1] - 1 ? G.res[1] - 1 : cy; cy = cy < 0 ? 0 : cy;
+  cz = cz > G.res[2] - 1 ? G.res[2] - 1 : cz; cz = cz < 0 ? 0 : cz;
+  return G.cells[(cz * G.res[1] + cy) * G.res[0] + cx];
+}
+
+// guiding_gpu.cuh:60-78 with e^(-2 kappa), 1 / kappa and the normalised axis taken from the record
+PT_HD f3 vmf_sample(const GuideLobeDev& lb, float ux, float uy) {
   float cos_theta;
-  if (kappa <= 1e-4f) {
+  if (lb.kappa <= 1e-4f) {
     cos_theta = 1.f - 2.f * ux;
   } else {
-    const float term = fexp(-2.f * kappa);
-    cos_theta = 1.f + flog(term + (1.f - term) * ux) * rcp(kappa);
+    cos_theta = 1.f + flog(lb.term + (1.f - lb.term) * ux) * lb.inv_kappa;
   }
   const float sin_theta = fsqrt(fmaxf(0.f, 1.f - cos_theta * cos_theta));
   const f3 local = mk3(cos2pi(uy) * sin_theta, sin2pi(uy) * sin_theta, cos_theta);
-  const f3 w = normalize_chk(mu);
+  const f3 w = ld3(lb.axis);
   const f3 up = fabsf(w.z) < 0.9999999f ? mk3(0.f, 0.f, 1.f) : mk3(1.f, 0.f, 0.f);
   const f3 u_axis = normalize_chk(cross(up, w));
   const f3 v_axis = cross(w, u_axis);
@@ -38,40 +53,78 @@ PT_HD f3 vmf_sample(f3 mu, float kappa, float ux, float uy) {
              u_axis.z * local.x + v_axis.z * local.y + w.z * local.z);
 }
 
-// guiding_gpu.cuh:80-84.  kappa / (4 pi sinh kappa) * exp(kappa mu.w) is evaluated in the
-// algebraically identical form kappa / (2 pi (1 - e^{-2 kappa})) * exp(kappa (mu.w - 1)),
-// which stays finite where sinhf/expf of the literal form overflow.
-PT_HD float vmf_pdf(f3 mu, float kappa, f3 wi) {
-  if (kappa <= 1e-4f) return 1.f / (4.f * kPi);
-  const float norm = kappa * rcp(2.f * kPi * (1.f - fexp(-2.f * kappa)));
-  return norm * fexp(kappa * (dot(mu, wi) - 1.f));
-}
-
-PT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
-
-// guiding_gpu.cuh:86-106 with ch = -1 (the only value the live path passes, optix_device.cu:615)
-PT_HD int guiding_choose_lobe(const GuideLobe* L, uint32_t lobe_num, float u) {
-  float sum = 0.f;
-  for (uint32_t i = 0; i < lobe_num; ++i) sum += L[i].weight;
+// guiding_gpu.cuh:86-106 with ch = -1 (the only value the live path passes, optix_device.cu:615): the first
+// lobe whose running weight sum reaches u * total.  The sums are the reference's own float additions, done once.
+PT_HD int guiding_choose_lobe(const GuideLobeDev* L, uint32_t lobe_num, float sum, float u) {
   if (sum <= 0.f) return -1;
   const float r = u * sum;
-  float acc = 0.f;
-  for (uint32_t i = 0; i < lobe_num; ++i) {
-    acc += L[i].weight;
-    if (r <= acc) return (int)i;
-  }
+  for (uint32_t i = 0; i < lobe_num; ++i)
+    if (r <= L[i].cdf) return (int)i;
   return (int)(lobe_num - 1);
 }
 
-// guiding_gpu.cuh:112-118
-PT_HD float guiding_mixture_pdf(const GuideLobe* L, uint32_t lobe_num, f3 wi) {
-  float sum = 0.f, pdf = 0.f;
+// guiding_gpu.cuh:80-84, 112-118.  kappa / (4 pi sinh kappa) * exp(kappa mu.w) in the algebraically identical form
+// kappa / (2 pi (1 - e^{-2 kappa})) * exp(kappa (mu.w - 1)), which stays finite where sinhf / expf of the literal
+// form overflow; the factor in front (times the lobe's weight) is the record's c, the exponential one exp2.
+PT_HD float guiding_mixture_pdf(const GuideLobeDev* L, uint32_t lobe_num, float sum, f3 wi) {
+  float pdf = 0.f;
   for (uint32_t i = 0; i < lobe_num; ++i) {
-    const float w = L[i].weight;
-    sum += w;
-    pdf += w * vmf_pdf(ld3(L[i].mu), L[i].kappa, wi);
+    const float e = L[i].kappa <= 1e-4f ? 1.0f : fexp2(L[i].k2 * (dot(ld3(L[i].mu), wi) - 1.f));
+    pdf += L[i].c * e;
   }
-  return sum > 0.f ? pdf / sum : 0.f;
+  return sum > 0.f ? pdf * rcp(sum) : 0.f;
+}
+
+// ---- host side: snapshot (optix/guiding_gpu.h:7-22 layouts) -> device records
+inline GuideLobeDev make_guide_lobe(const GuideLobe& l, float cdf) {
+  GuideLobeDev d;
+  for (int k = 0; k < 3; ++k) { d.mu[k] = l.mu[k]; d.rgb[k] = l.rgb[k]; }
+  d.kappa = l.kappa;
+  d.weight = l.weight;
+  d.cdf = cdf;
+  const double kp = (double)l.kappa;
+  if (l.kappa <= 1e-4f) {
+    d.c = (float)((double)l.weight / (4.0 * 3.14159265358979323846));
+    d.term = 1.0f;
+    d.inv_kappa = 0.0f;
+  } else {
+    d.c = (float)((double)l.weight * kp / (2.0 * 3.14159265358979323846 * (1.0 - exp(-2.0 * kp))));
+    d.term = (float)exp(-2.0 * kp);
+    d.inv_kappa = (float)(1.0 / kp);
+  }
+  d.k2 = (float)(kp * 1.4426950408889634);
+  const double len2 = (double)l.mu[0] * l.mu[0] + (double)l.mu[1] * l.mu[1] + (double)l.mu[2] * l.mu[2];
+  const double inv = len2 > 0.0 ? 1.0 / sqrt(len2) : 0.0;  // normalize_chk: a zero axis stays zero
+  for (int k = 0; k < 3; ++k) d.axis[k] = (float)((double)l.mu[k] * inv);
+  return d;
+}
+// regions[i] = {lobe range, total weight}; lobes in the snapshot's order
+inline void make_guide_records(const GuideRegion* regions, uint32_t nr, const GuideLobe* lobes, uint32_t nl,
+                               GuideRegionDev* out_regions, GuideLobeDev* out_lobes) {
+  for (uint32_t i = 0; i < nl; ++i) out_lobes[i] = make_guide_lobe(lobes[i], 0.0f);
+  for (uint32_t r = 0; r < nr; ++r) {
+    GuideRegionDev d{regions[r].lobe_ofs, regions[r].lobe_num, 0.0f, 0.0f};
+    if ((uint64_t)d.lobe_ofs + d.lobe_num > nl) d.lobe_num = d.lobe_ofs < nl ? nl - d.lobe_ofs : 0u;  // stay inside the array
+    float acc = 0.0f;
+    for (uint32_t i = 0; i < d.lobe_num; ++i) {  // the float additions of guiding_gpu.cuh:93-103, in their order
+      acc += lobes[d.lobe_ofs + i].weight;
+      out_lobes[d.lobe_ofs + i].cdf = acc;
+    }
+    d.sum = acc;
+    out_regions[r] = d;
+  }
+}
+// cells[c] = the record of the region grid[c] names, region id kept in pad; an empty cell has no lobes
+inline void make_guide_cells(const uint32_t* grid, size_t n_cells, const GuideRegionDev* regions, uint32_t nr,
+                             GuideRegionDev* cells) {
+  for (size_t c = 0; c < n_cells; ++c) {
+    GuideRegionDev d{0u, 0u, 0.0f, u2f(grid[c])};
+    if (grid[c] < nr) {
+      d = regions[grid[c]];
+      d.pad = u2f(grid[c]);
+    }
+    cells[c] = d;
+  }
 }
 
 }  // namespace pt

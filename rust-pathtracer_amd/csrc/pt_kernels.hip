@@ -866,38 +866,46 @@ void launch_extend(const RenderParams& p, int q, const LaunchCfg& c) {
   k_extend<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
   PT_KCHECK();
 }
+// GUIDED and TRAIN are compiled in separately: a guided render without a training ring (or the other way round)
+// does not carry the other's registers.
+template <bool GUIDED, bool TRAIN>
+static void launch_shade_t(const RenderParams& p, int q, const LaunchCfg& c) {
+  k_shade<GUIDED, TRAIN><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
+}
 void launch_shade(const RenderParams& p, int q, const LaunchCfg& c) {
-  if (p.guiding || p.train)
-    k_shade<true, true><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
-  else
-    k_shade<false, false><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
+  const bool g = p.guiding != 0, t = p.train != nullptr;
+  if (g && t) launch_shade_t<true, true>(p, q, c);
+  else if (g) launch_shade_t<true, false>(p, q, c);
+  else if (t) launch_shade_t<false, true>(p, q, c);
+  else launch_shade_t<false, false>(p, q, c);
   PT_KCHECK();
 }
 void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c) {
   k_occlude<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
   PT_KCHECK();
 }
+template <bool GUIDED, bool TRAIN>
+static void launch_bounce_t(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c, bool lds_scene,
+                            bool defer, size_t lds) {
+  if (defer) {
+    if (lds_scene) k_bounce_defer<GUIDED, TRAIN, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+    else k_bounce_defer<GUIDED, TRAIN, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+  } else {
+    if (lds_scene) k_bounce<GUIDED, TRAIN, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+    else k_bounce<GUIDED, TRAIN, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
+  }
+}
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c) {
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
   const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= 24u * 1024u;
   size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
-  const bool guided = p.guiding || p.train;
-  if (p.defer_shadow && !p.acc2) {
-    lds += (size_t)(c.threads / 64) * kDeferWords * sizeof(float);
-    if (guided) {
-      if (lds_scene) k_bounce_defer<true, true, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-      else k_bounce_defer<true, true, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-    } else {
-      if (lds_scene) k_bounce_defer<false, false, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-      else k_bounce_defer<false, false, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-    }
-  } else if (guided) {
-    if (lds_scene) k_bounce<true, true, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-    else k_bounce<true, true, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-  } else {
-    if (lds_scene) k_bounce<false, false, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-    else k_bounce<false, false, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact);
-  }
+  const bool defer = p.defer_shadow && !p.acc2;
+  if (defer) lds += (size_t)(c.threads / 64) * kDeferWords * sizeof(float);
+  const bool g = p.guiding != 0, t = p.train != nullptr;
+  if (g && t) launch_bounce_t<true, true>(p, qin, bounces, compact, c, lds_scene, defer, lds);
+  else if (g) launch_bounce_t<true, false>(p, qin, bounces, compact, c, lds_scene, defer, lds);
+  else if (t) launch_bounce_t<false, true>(p, qin, bounces, compact, c, lds_scene, defer, lds);
+  else launch_bounce_t<false, false>(p, qin, bounces, compact, c, lds_scene, defer, lds);
   PT_KCHECK();
 }
 // Profiling build only: copy out (and clear) the section counters; returns 0 in the shipped build.
@@ -1057,16 +1065,16 @@ __global__ void k_dbg_guiding(GuideView gv, int n, const float* pos, const float
   dir[3 * i] = dir[3 * i + 1] = dir[3 * i + 2] = 0.f;
   pdf_dir[i] = pdf_wi[i] = 0.f;
   if (rid < 0) return;
-  const GuideRegion R = gv.regions[rid];
+  const GuideRegionDev R = gv.regions[rid];
   if (R.lobe_num == 0) return;
-  const GuideLobe* L = gv.lobes + R.lobe_ofs;
-  const int li = guiding_choose_lobe(L, R.lobe_num, u3[3 * i]);
+  const GuideLobeDev* L = gv.lobes + R.lobe_ofs;
+  const int li = guiding_choose_lobe(L, R.lobe_num, R.sum, u3[3 * i]);
   lobe[i] = li;
-  pdf_wi[i] = guiding_mixture_pdf(L, R.lobe_num, w);
+  pdf_wi[i] = guiding_mixture_pdf(L, R.lobe_num, R.sum, w);
   if (li < 0) return;
-  const f3 g = vmf_sample(ld3(L[li].mu), L[li].kappa, u3[3 * i + 1], u3[3 * i + 2]);
+  const f3 g = vmf_sample(L[li], u3[3 * i + 1], u3[3 * i + 2]);
   dir[3 * i] = g.x; dir[3 * i + 1] = g.y; dir[3 * i + 2] = g.z;
-  pdf_dir[i] = guiding_mixture_pdf(L, R.lobe_num, g);
+  pdf_dir[i] = guiding_mixture_pdf(L, R.lobe_num, R.sum, g);
 }
 
 void launch_dbg_pcg(unsigned long long seed, int n, uint32_t* out_u, float* out_f, hipStream_t s) {

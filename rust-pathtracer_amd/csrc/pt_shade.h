@@ -212,6 +212,11 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
     const float area = 4.0f * sc.light_half[0] * sc.light_half[1];
     const f3 light_n = ld3(sc.light_normal);
 
+    // The guiding field's cell record is asked for here, well before the diffuse branch needs it, so that its
+    // trip to memory runs beside the next-event arithmetic (optix_device.cu:596-612 does the lookup in place).
+    GuideRegionDev guide_cell{0u, 0u, 0.0f, 0.0f};
+    if (GUIDED && sp.guiding) guide_cell = guiding_cell(gv, P);
+
     // optix_device.cu:495-548: next-event estimation towards the rectangle light
     f3 Lo = mk3(0.0f);
     {
@@ -294,30 +299,29 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
       f3 newDir = mk3(0.f);
       float cosTheta = 0.f, p_guided = 0.f, p_bsdf = 0.f;
       f3 lobe_rgb = mk3(1.0f);
-      const GuideLobe* lobes = nullptr;
+      const GuideLobeDev* lobes = nullptr;
       uint32_t lobe_num = 0;
+      float lobe_sum = 0.f;
       bool have_guiding = false;
       if (GUIDED && sp.guiding) {
-        const int region_id = guiding_region_id(gv, P);
-        if (region_id >= 0) {
-          const GuideRegion R = gv.regions[region_id];
-          if (R.lobe_num > 0) {
-            lobes = gv.lobes + R.lobe_ofs;
-            lobe_num = R.lobe_num;
-            have_guiding = true;
-          }
+        const GuideRegionDev R = guide_cell;
+        if (R.lobe_num > 0) {
+          lobes = gv.lobes + R.lobe_ofs;
+          lobe_num = R.lobe_num;
+          lobe_sum = R.sum;
+          have_guiding = true;
         }
       }
       bool used_guiding = false;
       if (have_guiding) {
-        const int lobe_idx = guiding_choose_lobe(lobes, lobe_num, next_rand(ps, rc));
+        const int lobe_idx = guiding_choose_lobe(lobes, lobe_num, lobe_sum, next_rand(ps, rc));
         if (lobe_idx >= 0) {
           const float ux = next_rand(ps, rc);
           const float uy = next_rand(ps, rc);
-          const GuideLobe lb = lobes[lobe_idx];
-          const f3 gdir = vmf_sample(ld3(lb.mu), lb.kappa, ux, uy);
+          const GuideLobeDev lb = lobes[lobe_idx];
+          const f3 gdir = vmf_sample(lb, ux, uy);
           const float cosG = fmaxf(dot(gdir, Ng), 0.0f);
-          const float p_g = guiding_mixture_pdf(lobes, lobe_num, gdir);
+          const float p_g = guiding_mixture_pdf(lobes, lobe_num, lobe_sum, gdir);
           const float p_b = cosG * kInvPi;
           const float ch2 = next_rand(ps, rc) * (p_g + p_b);
           if (ch2 < p_g) {
@@ -337,7 +341,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
         make_onb(Ng, tangent, bitangent);
         newDir = normalize_chk(tangent * local.x + bitangent * local.y + Ng * local.z);
         p_bsdf = cosTheta * kInvPi;
-        if (have_guiding) p_guided = guiding_mixture_pdf(lobes, lobe_num, newDir);
+        // (the reference also evaluates the mixture pdf of this direction, optix_device.cu:647, and never uses it)
       }
       ps.o = P + Ng * 1e-3f;
       ps.d = newDir;

@@ -126,6 +126,13 @@ PT_HD float fexp(float x) {
   return expf(x);
 #endif
 }
+PT_HD float fexp2(float x) {
+#if PT_ON_DEVICE
+  return __builtin_amdgcn_exp2f(x);
+#else
+  return exp2f(x);
+#endif
+}
 PT_HD float flog(float x) {
 #if PT_ON_DEVICE
   return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
@@ -219,14 +226,35 @@ PT_HD uint32_t train_digest(const TrainRec& r) {
   return h << 1;
 }
 
+// The field as the kernels read it (built from the snapshot at upload time, pt_guiding.h: make_guide_lobes).
+// A lobe is four 16-byte words with everything that does not depend on the query already worked out: the running
+// weight sum for the lobe choice, weight x normalisation and kappa x log2(e) for the mixture pdf, e^(-2 kappa) and
+// 1 / kappa for the sampler, the unit axis.  A region is its lobe range and total weight.
+struct alignas(16) GuideLobeDev {
+  float mu[3]; float kappa;          // as given (the pdf of guiding_gpu.cuh:80-84 uses mu unnormalised)
+  float cdf, c, k2, term;            // sum of weights up to and including this lobe; weight * kappa / (2 pi (1 - e^-2k))
+                                     // (weight / 4 pi for kappa <= 1e-4); kappa * log2(e); e^(-2 kappa)
+  float rgb[3]; float inv_kappa;
+  float axis[3]; float weight;       // mu normalised
+};
+struct alignas(16) GuideRegionDev {
+  uint32_t lobe_ofs, lobe_num;
+  float sum, pad;                    // total weight of the region's lobes
+};
+static_assert(sizeof(GuideLobeDev) == 64 && sizeof(GuideRegionDev) == 16, "device guiding records");
+
 // Device view of the guiding field (optix/guiding_gpu.cuh:18-22).
 struct GuideView {
-  const GuideRegion* regions;
-  const GuideLobe* lobes;
-  const uint32_t* grid;
+  const GuideRegionDev* regions;
+  const GuideLobeDev* lobes;
+  const uint32_t* grid;          // region id per cell, 0xFFFFFFFF = none (guiding_gpu.cuh:35-45)
+  // the same grid with each cell's region record in place (pad = region id as bits; lobe_num = 0 for none):
+  // one load instead of two dependent ones on the shading path
+  const GuideRegionDev* cells;
   int res[3];
   float gmin[3];
   float cell[3];
+  float inv_cell[3];  // 1 / cell (0 where the field is flat along the axis)
 };
 
 struct SceneView {

@@ -6,6 +6,8 @@
 // the HIP wavefront kernels of pt_kernels.hip.
 #include "renderer.h"
 
+#include "pt_guiding.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -248,9 +250,16 @@ void upload_guide(State& s) {
           if (grid[idx] == 0xFFFFFFFFu) grid[idx] = r;  // first region wins
         }
   }
-  upload(s.d_regions, hreg);
-  upload(s.d_lobes, hlobe);
+  std::vector<GuideRegionDev> dreg(nr);
+  std::vector<GuideLobeDev> dlobe(nl);
+  make_guide_records(hreg.data(), nr, hlobe.data(), nl, dreg.data(), dlobe.data());
+  upload(s.d_regions, dreg);
+  upload(s.d_lobes, dlobe);
   upload(s.d_grid, grid);
+  std::vector<GuideRegionDev> cells(grid.size());
+  make_guide_cells(grid.data(), grid.size(), dreg.data(), nr, cells.data());
+  upload(s.d_cells, cells);
+  s.guide.cells = s.d_cells;
   s.guide.regions = s.d_regions;
   s.guide.lobes = s.d_lobes;
   s.guide.grid = s.d_grid;
@@ -258,6 +267,7 @@ void upload_guide(State& s) {
     s.guide.res[k] = res[k];
     s.guide.gmin[k] = bmin[k];
     s.guide.cell[k] = cell[k];
+    s.guide.inv_cell[k] = cell[k] > 0.f ? 1.0f / cell[k] : 0.0f;
   }
   s.guide_valid = nl > 0;
 }
@@ -865,7 +875,7 @@ State::~State() {
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);
   dev_free(shared_acc); dev_free(shared_acc2); dev_free(shared_n);
   dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_sum4); dev_free(d_peer);
-  dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid);
+  dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid); dev_free(d_cells);
   if (h_counters) (void)hipHostFree(h_counters);
   for (int i = 0; i < 2; ++i) if (ev_slot[i]) (void)hipEventDestroy(ev_slot[i]);
   if (ev_begin) (void)hipEventDestroy(ev_begin);

@@ -89,8 +89,9 @@ struct State {
   TrainRec* d_train = nullptr;
   uint32_t* d_train_idx = nullptr;
   uint32_t train_capacity = 0;
-  GuideRegion* d_regions = nullptr;
-  GuideLobe* d_lobes = nullptr;
+  GuideRegionDev* d_regions = nullptr;
+  GuideLobeDev* d_lobes = nullptr;
+  GuideRegionDev* d_cells = nullptr;
   uint32_t* d_grid = nullptr;
   GuideView guide{};
   bool guide_valid = false;

@@ -23,6 +23,9 @@ SceneView g_sv;
 CameraView g_cam;
 std::vector<GuideRegion> g_regions;
 std::vector<GuideLobe> g_lobes;
+std::vector<GuideRegionDev> g_regions_dev;
+std::vector<GuideLobeDev> g_lobes_dev;
+std::vector<GuideRegionDev> g_cells_dev;
 std::vector<uint32_t> g_grid;
 GuideView g_gv;
 int g_guiding = 0;
@@ -151,8 +154,16 @@ void hc_guide_set(const float* regions8, int nr, const float* lobes8, int nl, co
   memcpy(g_regions.data(), regions8, (size_t)nr * 32);
   memcpy(g_lobes.data(), lobes8, (size_t)nl * 32);
   g_grid.assign(grid, grid + (size_t)res[0] * res[1] * res[2]);
-  g_gv.regions = g_regions.data(); g_gv.lobes = g_lobes.data(); g_gv.grid = g_grid.data();
-  for (int k = 0; k < 3; ++k) { g_gv.res[k] = res[k]; g_gv.gmin[k] = gmin[k]; g_gv.cell[k] = cell[k]; }
+  g_regions_dev.resize((size_t)nr); g_lobes_dev.resize((size_t)nl);
+  make_guide_records(g_regions.data(), (uint32_t)nr, g_lobes.data(), (uint32_t)nl, g_regions_dev.data(), g_lobes_dev.data());
+  g_cells_dev.resize(g_grid.size());
+  make_guide_cells(g_grid.data(), g_grid.size(), g_regions_dev.data(), (uint32_t)nr, g_cells_dev.data());
+  g_gv.regions = g_regions_dev.data(); g_gv.lobes = g_lobes_dev.data(); g_gv.grid = g_grid.data();
+  g_gv.cells = g_cells_dev.data();
+  for (int k = 0; k < 3; ++k) {
+    g_gv.res[k] = res[k]; g_gv.gmin[k] = gmin[k]; g_gv.cell[k] = cell[k];
+    g_gv.inv_cell[k] = cell[k] > 0.f ? 1.0f / cell[k] : 0.0f;
+  }
   g_guiding = enabled;
 }
 

@@ -13,6 +13,21 @@ L = gpu.lib()
 L.pt_set_pipeline(1)
 L.pt_set_frame(0)
 L.pt_reset_ray_counts()
+if os.environ.get("GUIDED"):  # configuration 3: seeded synthetic field, 8 x 8 x 8 regions of 4 lobes
+    rng = np.random.default_rng(1234)
+    regions, lobes = [], []
+    step = np.array([2, 2, 2.0]) / 8
+    for z in range(8):
+        for y in range(8):
+            for x in range(8):
+                bmin = np.array([-1, -1, 0.0]) + step * np.array([x, y, z])
+                regions.append(list(bmin) + list(bmin + step) + [len(lobes), 4])
+                for _ in range(4):
+                    mu = rng.normal(size=3); mu /= np.linalg.norm(mu)
+                    lobes.append(list(mu) + [rng.uniform(1, 50), rng.uniform(0.01, 1), 1, 1, 1])
+    L.guiding_set_grid_res(8, 8, 8)
+    gpu.upload_snapshot(np.array(regions, np.float32), np.array(lobes, np.float32))
+    L.guiding_set_enabled(1)
 gpu.render_rgb(w, h, spp)
 buf = (C.c_uint64 * 64)()
 n = L.pt_dbg_profile_counters(buf)
