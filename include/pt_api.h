@@ -273,6 +273,28 @@ PT_EXPORT int  pt_scene_triangles(const float* vertices, int n_vertices, const u
  * of src/guiding.rs:196-219 in one call); used by multi-GPU hosts that gather every rank's ring on one rank. */
 PT_EXPORT void pt_pgl_samples_add_batch(pgl_samples_t samples, const TrainSample* records, uint32_t count);
 
+/* Training from statistics binned on the GPU.  The reference copies the whole training ring to the host (10.5 MB)
+ * and adds its records one call at a time (src/guiding.rs:194-220); the trainer here only ever needs, per region and
+ * lobe of its field, sums over the samples assigned to it.  pt_guiding_bin_train_samples_device takes those sums on
+ * the device: every valid record of the current renderer's ring is assigned as pgl_field_update would assign it
+ * (region by position, lobe by the largest dot(dir_in, axis)) and added to a table of 64-bit fixed-point integers,
+ *   d_bins[(region * PT_PGL_BIN_LOBES + lobe) * PT_PGL_BIN_WORDS + k],
+ *   k = 0..2 sum of weight * dir_in, 3 sum of weight, 4..6 sum of contrib (x 2^PT_PGL_BIN_SHIFT), 7 number of samples,
+ * in device memory (the caller zeroes it; regions = product of the field's resolution, pt_pgl_field_layout).
+ * Integer sums do not depend on the order of addition: the tables of several GPUs can be added (RCCL all-reduce of
+ * int64) and every rank that applies the total to its own copy of the field gets the same field, bit for bit.
+ * pt_pgl_field_update_binned applies a table (host memory) to the field; pt_pgl_field_update_from_ring does
+ * bin + copy + update + ring reset for the current renderer (and its sample shards) in one call.
+ * Return 0, or -1 without a renderer, ring or field. */
+#define PT_PGL_BIN_LOBES 6
+#define PT_PGL_BIN_WORDS 8
+#define PT_PGL_BIN_SHIFT 24
+PT_EXPORT int  pt_pgl_field_layout(pgl_field_t field, float bmin[3], float bmax[3], int res[3], float* lobe_axes,
+                                   uint32_t* regions);
+PT_EXPORT void pt_pgl_field_update_binned(pgl_field_t field, const long long* bins);
+PT_EXPORT int  pt_guiding_bin_train_samples_device(pgl_field_t field, long long* d_bins);
+PT_EXPORT int  pt_pgl_field_update_from_ring(pgl_field_t field);
+
 /* Scene input beyond the built-in box (the reference has none: its quads are hard-coded,
  * optix_wrapper.cpp:379-489).  pt_scene_load_obj reads a Wavefront OBJ file and the material library it names:
  * v, f (polygons are fanned; v, v/vt, v//vn, v/vt/vn; negative indices), usemtl; Kd = base colour, Ke =

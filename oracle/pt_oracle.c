@@ -539,6 +539,7 @@ typedef struct {
   uint64_t* shadow_rays;
 } ch_ctx;
 
+static int g_no_roulette = 0; /* orc_set_roulette(0): instrumentation for the unbiasedness test, never the reference's behaviour */
 /* optix_device.cu:660-672 (and the identical block 468-480): depth / Russian roulette.
  * Returns 1 when the caller must return immediately. */
 static void depth_and_rr(orc_prd* prd, const ch_ctx* c) {
@@ -546,6 +547,10 @@ static void depth_and_rr(orc_prd* prd, const ch_ctx* c) {
   if (prd->depth >= c->max_depth) { prd->done = 1; return; }
   if (prd->depth >= c->max_depth - 2) {
     float p = fmaxf(prd->throughput[0], fmaxf(prd->throughput[1], prd->throughput[2]));
+    if (g_no_roulette) {  /* test instrumentation: the draw is taken, the path always goes on, nothing is divided */
+      (void)orc_next_rand(prd, c->frame);
+      return;
+    }
     if (orc_next_rand(prd, c->frame) > p) { prd->done = 1; return; }
     st3(prd->throughput, div3(ld3(prd->throughput), fmaxf(p, 1e-3f)));
   }
@@ -786,6 +791,7 @@ void orc_closesthit(orc_prd* prd, const orc_hit* hit, int frame, int max_depth,
  * implementation, and tests use the marks to tell these pixels from real disagreements. */
 static unsigned char* g_on_plane_flags = NULL;
 void orc_set_on_plane_flags(unsigned char* per_pixel) { g_on_plane_flags = per_pixel; }
+void orc_set_roulette(int on) { g_no_roulette = on ? 0 : 1; }
 static int origin_on_a_plane(const float o[3]) {
   for (int t = 0; t < g_ntri; ++t) {
     const f3 n = normalize3(ld3(g_normals + 3 * t));

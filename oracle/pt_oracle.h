@@ -159,6 +159,9 @@ void  orc_guiding_build_grid(const orc_region* regions, uint32_t n_regions, cons
  * for every pixel one of whose radiance rays starts within 1e-5 of the plane of some triangle (the reference's
  * 1e-3 origin offset puts a path that leaves the glass box through its bottom face exactly on the floor). */
 void orc_set_on_plane_flags(unsigned char* per_pixel);
+/* Test instrumentation: 0 lets every path pass the roulette of optix_device.cu:660-672 with its throughput unchanged
+ * (the random number is still drawn); 1 (default) is the reference's behaviour. */
+void orc_set_roulette(int on);
 int orc_render(const orc_render_args* a, float* out_rgb, float* out_bayer,
                int* sample_counts, uint64_t ray_counts[2]);
 

@@ -61,6 +61,16 @@ int field_res() {
   return r < 1 ? 1 : (r > 64 ? 64 : r);
 }
 
+// the assignment directions follow the accumulated moments
+void refresh_axes(StubField& f) {
+  for (StubRegion& reg : f.regions)
+    for (StubLobe& lb : reg.lobes) {
+      const double len = std::sqrt(lb.r[0] * lb.r[0] + lb.r[1] * lb.r[1] + lb.r[2] * lb.r[2]);
+      if (lb.w > 0 && len > 1e-12)
+        for (int k = 0; k < 3; ++k) lb.mu[k] = (float)(lb.r[k] / len);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -137,15 +147,51 @@ void pgl_field_update(pgl_field_t field_handle, pgl_samples_t samples_handle) {
     lb.w += it.weight;
     lb.count += 1.0;
   }
-  // refresh the assignment directions from the accumulated moments
-  for (StubRegion& reg : f->regions)
-    for (StubLobe& lb : reg.lobes) {
-      const double len = std::sqrt(lb.r[0] * lb.r[0] + lb.r[1] * lb.r[1] + lb.r[2] * lb.r[2]);
-      if (lb.w > 0 && len > 1e-12)
-        for (int k = 0; k < 3; ++k) lb.mu[k] = (float)(lb.r[k] / len);
-    }
+  refresh_axes(*f);
   f->trained = true;
   s->items.clear();  // openpgl_bridge.cpp:122-123
+}
+
+// ---- training from statistics binned on the GPU (no counterpart in the reference, which moves the whole ring to
+// the host and adds its records one call at a time, src/guiding.rs:194-220).  pgl_field_update only ever needs,
+// per region and lobe, the sums over the samples assigned to it; those sums are taken on the device
+// (pt_kernels.hip: k_bin_train) as 64-bit fixed-point integers, so they do not depend on the order of addition and
+// the tables of several GPUs add up exactly.
+//   bins[(region * PT_PGL_BIN_LOBES + lobe) * PT_PGL_BIN_WORDS + k]:
+//   k = 0..2 sum of weight * dir_in, 3 sum of weight, 4..6 sum of the sample colour (all x 2^24), 7 number of samples
+int pt_pgl_field_layout(pgl_field_t field_handle, float bmin[3], float bmax[3], int res[3], float* lobe_axes, uint32_t* regions) {
+  StubField* f = static_cast<StubField*>(field_handle);
+  if (!f) return -1;
+  for (int k = 0; k < 3; ++k) {
+    if (bmin) bmin[k] = f->bmin[k];
+    if (bmax) bmax[k] = f->bmax[k];
+    if (res) res[k] = f->res[k];
+  }
+  if (regions) *regions = (uint32_t)f->regions.size();
+  if (lobe_axes)  // the directions samples are assigned by, [region][lobe][3]
+    for (size_t r = 0; r < f->regions.size(); ++r)
+      for (int l = 0; l < kLobes; ++l) memcpy(lobe_axes + (r * kLobes + l) * 3, f->regions[r].lobes[l].mu, sizeof(float) * 3);
+  return 0;
+}
+
+void pt_pgl_field_update_binned(pgl_field_t field_handle, const long long* bins) {
+  StubField* f = static_cast<StubField*>(field_handle);
+  if (!f || !bins) return;
+  static_assert(PT_PGL_BIN_LOBES == kLobes, "bin table and field disagree on the lobes per region");
+  const double inv = 1.0 / (double)(1ll << PT_PGL_BIN_SHIFT);
+  for (size_t r = 0; r < f->regions.size(); ++r)
+    for (int l = 0; l < kLobes; ++l) {
+      const long long* b = bins + (r * kLobes + l) * PT_PGL_BIN_WORDS;
+      StubLobe& lb = f->regions[r].lobes[l];
+      for (int k = 0; k < 3; ++k) {
+        lb.r[k] += (double)b[k] * inv;
+        lb.rgb[k] += (double)b[4 + k] * inv;
+      }
+      lb.w += (double)b[3] * inv;
+      lb.count += (double)b[7];
+    }
+  refresh_axes(*f);
+  f->trained = true;
 }
 
 void pgl_field_snapshot(pgl_field_t field_handle, const struct pgl_region** regions, uint32_t* region_count,

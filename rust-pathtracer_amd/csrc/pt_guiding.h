@@ -75,6 +75,50 @@ PT_HD float guiding_mixture_pdf(const GuideLobeDev* L, uint32_t lobe_num, float 
   return sum > 0.f ? pdf * rcp(sum) : 0.f;
 }
 
+// ---- training statistics binned on the device
+// The trainer's field as the binning kernel needs it: bounds, resolution, and (separately) the axis of every lobe.
+struct BinField {
+  float bmin[3], bmax[3];
+  int res[3];
+};
+constexpr int kBinLobes = 6, kBinWords = 8, kBinShift = 24;
+
+// One ring record -> the (region, lobe) it trains and its eight fixed-point addends; false when the trainer would
+// drop it (torn or empty slot, outside the field, weight not positive and finite).  The assignment repeats the
+// trainer's own float arithmetic operation for operation (no fused multiply-adds), so both agree on every record.
+PT_HD bool bin_train_record(const TrainRec& rec, const BinField& f, const float* axes, uint32_t& bin, long long add[kBinWords]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  if (rec.is_delta == 0xffffffffu || (rec.is_delta & ~1u) != train_digest(rec)) return false;
+  int c[3];
+  for (int k = 0; k < 3; ++k) {
+    const float ext = f.bmax[k] - f.bmin[k];
+    if (rec.position[k] < f.bmin[k] || rec.position[k] > f.bmax[k] || !(ext > 0.f)) return false;
+    c[k] = (int)((rec.position[k] - f.bmin[k]) / ext * (float)f.res[k]);
+    if (c[k] >= f.res[k]) c[k] = f.res[k] - 1;
+  }
+  const float weight = (rec.contrib[0] + rec.contrib[1] + rec.contrib[2]) / 3.0f;
+  if (!(weight > 0.f) || !(weight <= 3.4028234663852886e38f)) return false;
+  const uint32_t region = (uint32_t)((c[2] * f.res[1] + c[1]) * f.res[0] + c[0]);
+  const float* mu = axes + (size_t)region * kBinLobes * 3;
+  int best = 0;
+  float best_d = -2.f;
+  for (int l = 0; l < kBinLobes; ++l) {
+    const float d = rec.dir_in[0] * mu[3 * l] + rec.dir_in[1] * mu[3 * l + 1] + rec.dir_in[2] * mu[3 * l + 2];
+    if (d > best_d) { best_d = d; best = l; }
+  }
+  bin = region * kBinLobes + (uint32_t)best;
+  const double scale = (double)(1ll << kBinShift);
+  for (int k = 0; k < 3; ++k) {
+    add[k] = (long long)__builtin_rint((double)weight * (double)rec.dir_in[k] * scale);
+    add[4 + k] = (long long)__builtin_rint((double)rec.contrib[k] * scale);
+  }
+  add[3] = (long long)__builtin_rint((double)weight * scale);
+  add[7] = 1;
+  return true;
+}
+
 // ---- host side: snapshot (optix/guiding_gpu.h:7-22 layouts) -> device records
 inline GuideLobeDev make_guide_lobe(const GuideLobe& l, float cdf) {
   GuideLobeDev d;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pt_types.h"
+#include "pt_guiding.h"
 
 namespace pt {
 
@@ -60,6 +61,8 @@ struct LaunchCfg {
 // One wavefront iteration, staged: qin -> generate -> qout; extend / shade / occlude over qout
 // (occlude also clears qin's counter for the next generate pass).
 void launch_generate(const RenderParams& p, int qin, const LaunchCfg& c);
+void launch_bin_train(const TrainRec* ring, uint32_t capacity, const BinField& field, const float* d_axes, long long* d_bins,
+                      hipStream_t stream);
 void launch_extend(const RenderParams& p, int q, const LaunchCfg& c);
 void launch_shade(const RenderParams& p, int q, const LaunchCfg& c);
 void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c);

@@ -38,6 +38,17 @@ extern __shared__ StackEntry g_lds_stack[];
 
 #ifdef PT_PROFILE
 __device__ unsigned long long g_prof_global[64];
+__device__ __forceinline__ void prof_begin() {
+  if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
+  __syncthreads();
+}
+__device__ __forceinline__ void prof_end() {
+  __syncthreads();
+  if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
+}
+#else
+__device__ __forceinline__ void prof_begin() {}
+__device__ __forceinline__ void prof_end() {}
 #endif
 
 // Per-lane traversal stack in LDS, entry (level, lane) at [level * blockDim + lane]:
@@ -182,6 +193,27 @@ __device__ __forceinline__ void flush_train_count(const RenderParams& p, uint32_
   if ((threadIdx.x & 63u) == 0u && captured && p.train_write_idx) atomicAdd(p.train_write_idx, captured);
 }
 
+// Training statistics per (region, lobe) of the trainer's field, straight from the ring (pt_guiding.h).
+__global__ void __launch_bounds__(256) k_bin_train(const TrainRec* ring, uint32_t capacity, BinField field, const float* axes,
+                                                   unsigned long long* bins) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += gridDim.x * blockDim.x) {
+    const TrainRec rec = ring[i];
+    uint32_t bin;
+    long long add[kBinWords];
+    if (!bin_train_record(rec, field, axes, bin, add)) continue;
+    // two's-complement addition: the unsigned atomic adds signed addends exactly
+    for (int k = 0; k < kBinWords; ++k)
+      if (add[k] != 0) atomicAdd(&bins[(size_t)bin * kBinWords + k], (unsigned long long)add[k]);
+  }
+}
+void launch_bin_train(const TrainRec* ring, uint32_t capacity, const BinField& field, const float* d_axes, long long* d_bins,
+                      hipStream_t stream) {
+  if (capacity == 0) return;
+  const int blocks = (int)std::min<uint32_t>((capacity + 255u) / 256u, 2048u);
+  k_bin_train<<<blocks, 256, 0, stream>>>(ring, capacity, field, d_axes, reinterpret_cast<unsigned long long*>(d_bins));
+  PT_KCHECK();
+}
+
 // ------------------------------------------------------------------------- generate
 __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
   constexpr int ITEMS = 4;
@@ -252,6 +284,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
   ts.finish();
   f3 ro = mk3(0.f), rd = mk3(0.f);
   uint32_t idx = 0xffffffffu;  // queue position of the lane's ray, none yet
+  prof_begin();
   for (;;) {
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -271,13 +304,21 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
     } else if (n_idle == 64u) {
       break;
     }
-    if (idx != 0xffffffffu && ts.wants_node()) ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
-    if (idx != 0xffffffffu && ts.wants_tri()) ts.tri_step(p.scene, ro, rd, 0.0f, false);
+    if (idx != 0xffffffffu) { PT_PROF(PF_BOUNCE); }
+    if (idx != 0xffffffffu && ts.wants_node()) {
+      PT_PROF(PF_NODE);
+      ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
+    }
+    if (idx != 0xffffffffu && ts.wants_tri()) {
+      PT_PROF(PF_TRI);
+      ts.tri_step(p.scene, ro, rd, 0.0f, false);
+    }
     if (idx != 0xffffffffu && ts.done()) {
       p.hits[idx] = q4{u2f((uint32_t)ts.hit.prim), ts.hit.t, ts.hit.b1, ts.hit.b2};
       idx = 0xffffffffu;
     }
   }
+  prof_end();
 }
 
 // ---------------------------------------------------------------------------- shade
@@ -339,6 +380,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   ts.finish();
   f3 ro = mk3(0.f), rd = mk3(0.f);
   uint32_t idx = 0xffffffffu;
+  prof_begin();
   for (;;) {  // same scheme as k_extend; records without a shadow ray (tmax < 0) finish at once
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -361,8 +403,15 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
     } else if (n_idle == 64u) {
       break;
     }
-    if (idx != 0xffffffffu && ts.wants_node()) ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
-    if (idx != 0xffffffffu && ts.wants_tri() && ts.tri_step(p.scene, ro, rd, 0.0f, true)) ts.finish();
+    if (idx != 0xffffffffu) { PT_PROF(PF_SHADOW); }
+    if (idx != 0xffffffffu && ts.wants_node()) {
+      PT_PROF(PF_SH_NODE);
+      ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
+    }
+    if (idx != 0xffffffffu && ts.wants_tri()) {
+      PT_PROF(PF_SH_TRI);
+      if (ts.tri_step(p.scene, ro, rd, 0.0f, true)) ts.finish();
+    }
     if (idx != 0xffffffffu && ts.done()) {
       if (ts.hit.prim < 0) {
         const uint32_t pixel = f2u(p.sh_d[idx].w);
@@ -376,6 +425,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   }
   for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
   if (lane == 0u && traced) atomicAdd(&p.ray_counters[1], (unsigned long long)traced);
+  prof_end();
 }
 
 // ---------------------------------------------------------------------------- fused

@@ -998,6 +998,61 @@ void guiding_map_train_samples(const TrainSample** samples, uint32_t* count) {
   if (samples) *samples = host.data();
   if (count) *count = (uint32_t)host.size();
 }
+// Training statistics taken on the device (include/pt_api.h).  d_bins lives on the current renderer's GPU.
+static int bin_state_ring(State& st, const BinField& bf, const std::vector<float>& axes, long long* d_bins) {
+  if (!st.d_train || st.train_capacity == 0) return -1;
+  HIP_CHECK(hipSetDevice(st.device));
+  float* d_axes = dev_alloc<float>(axes.size());
+  HIP_CHECK(hipMemcpyAsync(d_axes, axes.data(), axes.size() * sizeof(float), hipMemcpyHostToDevice, st.stream));
+  launch_bin_train(reinterpret_cast<const TrainRec*>(st.d_train), st.train_capacity, bf, d_axes, d_bins, st.stream);
+  HIP_CHECK(hipStreamSynchronize(st.stream));
+  dev_free(d_axes);
+  return 0;
+}
+static bool bin_layout(pgl_field_t field, BinField& bf, std::vector<float>& axes, uint32_t& regions) {
+  if (pt_pgl_field_layout(field, bf.bmin, bf.bmax, bf.res, nullptr, &regions) != 0 || regions == 0) return false;
+  axes.resize((size_t)regions * kBinLobes * 3);
+  return pt_pgl_field_layout(field, nullptr, nullptr, nullptr, axes.data(), nullptr) == 0;
+}
+int pt_guiding_bin_train_samples_device(pgl_field_t field, long long* d_bins) {
+  static_assert(kBinLobes == PT_PGL_BIN_LOBES && kBinWords == PT_PGL_BIN_WORDS && kBinShift == PT_PGL_BIN_SHIFT, "bin table layout");
+  if (!g_handle || !field || !d_bins) return -1;
+  BinField bf;
+  std::vector<float> axes;
+  uint32_t regions = 0;
+  if (!bin_layout(field, bf, axes, regions)) return -1;
+  return bin_state_ring(*g_handle, bf, axes, d_bins);
+}
+int pt_pgl_field_update_from_ring(pgl_field_t field) {
+  if (!g_handle || !field) return -1;
+  BinField bf;
+  std::vector<float> axes;
+  uint32_t regions = 0;
+  if (!bin_layout(field, bf, axes, regions)) return -1;
+  const size_t words = (size_t)regions * kBinLobes * kBinWords;
+  std::vector<long long> total(words, 0), part(words);
+  std::vector<State*> states{g_handle};
+  for (State* sh : g_shards)
+    if (sh) states.push_back(sh);
+  int binned = 0;
+  for (State* st : states) {  // every sample shard has its own ring on its own GPU: integer tables add up exactly
+    if (!st->d_train || st->train_capacity == 0) continue;
+    HIP_CHECK(hipSetDevice(st->device));
+    long long* d_bins = dev_alloc<long long>(words);
+    HIP_CHECK(hipMemsetAsync(d_bins, 0, words * sizeof(long long), st->stream));
+    if (bin_state_ring(*st, bf, axes, d_bins) == 0) {
+      HIP_CHECK(hipMemcpy(part.data(), d_bins, words * sizeof(long long), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < words; ++i) total[i] += part[i];
+      binned++;
+    }
+    dev_free(d_bins);
+  }
+  HIP_CHECK(hipSetDevice(g_handle->device));
+  if (!binned) return -1;
+  pt_pgl_field_update_binned(field, total.data());
+  guiding_reset_train_write_idx();
+  return 0;
+}
 void guiding_reset_train_write_idx(void) {
   if (!g_handle) return;
   std::vector<State*> states{g_handle};

@@ -73,6 +73,11 @@ SIGNATURES = {
     "pgl_samples_add_surface": (None, [C.c_void_p, _fp, _fp, _fp, C.c_int]),
     "pgl_field_update": (None, [C.c_void_p, C.c_void_p]),
     "pt_pgl_samples_add_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "pt_pgl_field_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
+    "pt_pgl_field_update_binned": (None, [C.c_void_p, C.c_void_p]),
+    "pt_guiding_bin_train_samples_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pt_pgl_field_update_from_ring": (C.c_int, [C.c_void_p]),
     "pgl_field_snapshot": (None, [C.c_void_p, C.POINTER(C.POINTER(PglRegion)), _u32p,
                                   C.POINTER(C.POINTER(PglLobe)), _u32p]),
     "pt_set_mode": (None, [C.c_int]),
@@ -334,6 +339,33 @@ class GuidingField:
         if len(records):
             L.pt_pgl_samples_add_batch(self.samples, records.ctypes.data_as(C.c_void_p), len(records))
         L.pgl_field_update(self.field, self.samples)
+
+    BIN_LOBES, BIN_WORDS, BIN_SHIFT = 6, 8, 24
+
+    def layout(self):
+        """(bmin[3], bmax[3], res[3], axes (regions, 6, 3) float32): what assigning a sample to a region and lobe needs."""
+        L = lib()
+        bmin, bmax, res, n = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_int * 3)(), C.c_uint32()
+        if L.pt_pgl_field_layout(self.field, bmin, bmax, res, None, C.byref(n)) != 0:
+            raise RuntimeError("pt_pgl_field_layout failed")
+        axes = np.zeros((n.value, self.BIN_LOBES, 3), np.float32)
+        L.pt_pgl_field_layout(self.field, None, None, None, _f(axes), None)
+        return np.array(bmin[:], np.float32), np.array(bmax[:], np.float32), np.array(res[:], np.int32), axes
+
+    def update_binned(self, bins):
+        """bins: int64 (regions * 6 * 8) fixed-point sums per region and lobe (pt_guiding_bin_train_samples_device)."""
+        bins = np.ascontiguousarray(bins, np.int64)
+        lib().pt_pgl_field_update_binned(self.field, bins.ctypes.data_as(C.c_void_p))
+
+    def bin_ring_device(self, d_bins_ptr):
+        """Adds the current renderer's training ring into the int64 table at device address d_bins_ptr."""
+        if lib().pt_guiding_bin_train_samples_device(self.field, C.c_void_p(d_bins_ptr)) != 0:
+            raise RuntimeError("pt_guiding_bin_train_samples_device failed")
+
+    def update_from_ring(self):
+        """Bin on the GPU, copy the table, update, empty the ring: the whole of src/guiding.rs:194-236 in one call."""
+        if lib().pt_pgl_field_update_from_ring(self.field) != 0:
+            raise RuntimeError("pt_pgl_field_update_from_ring failed")
 
     def snapshot(self):
         """(regions (n, 8) float32, lobes (m, 8) float32) in the layout upload_snapshot takes; the two integer

@@ -130,6 +130,7 @@ def lib():
     L.orc_render.restype = C.c_int
     L.orc_render.argtypes = [C.POINTER(RenderArgs), fp, fp, ip, C.POINTER(C.c_uint64)]
     L.orc_set_on_plane_flags.argtypes = [C.c_void_p]
+    L.orc_set_roulette.argtypes = [C.c_int]
     L.orc_cfa_at.restype = C.c_int
     L.orc_cfa_at.argtypes = [C.c_int] * 3
     L.orc_demosaic_amaze.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp]

@@ -593,6 +593,48 @@ def test_guiding_loop_through_the_helper(gpu):
         gpu.render_rgb(44, 28, 1)  # a renderer without a ring for the tests that follow
 
 
+def test_training_statistics_binned_on_the_gpu(gpu):
+    """pt_guiding_bin_train_samples_device against tests/binning.py on the records guiding_map_train_samples
+    returns for the same ring: the same int64 table, every word; and the one-call update (bin, copy 24 KB, update,
+    reset) trains the field the record-by-record path of src/guiding.rs:194-236 trains."""
+    import torch
+    import binning
+    from ptamd import sharded
+    L = gpu.lib()
+    L.guiding_set_train_buffer_size(1 << 14)
+    a, b = gpu.GuidingField((-1, -1, 0), (1, 1, 2)), gpu.GuidingField((-1, -1, 0), (1, 1, 2))
+    try:
+        for batch in range(2):  # the second batch is assigned by axes the first one moved
+            L.pt_set_frame(40 + batch)
+            gpu.render_rgb(52, 36, 32)
+            rec = gpu.train_samples()
+            assert len(rec) > 0.9 * (1 << 14)
+            want = binning.bin_records(rec, *b.layout())
+            table = torch.zeros(want.size, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            b.bin_ring_device(table.data_ptr())
+            got = table.cpu().numpy()
+            assert 0.9 * len(rec) < got[7::8].sum() <= len(rec)  # records of weight zero or outside the field train nothing
+            assert np.array_equal(got, want)
+            a.update(rec)
+            b.update_from_ring()
+            assert len(gpu.train_samples()) == 0  # the ring was emptied
+            (ra, la), (rb, lb) = a.snapshot(), b.snapshot()
+            assert np.array_equal(ra, rb) and la.shape == lb.shape and np.allclose(la, lb, rtol=2e-5, atol=2e-6)
+        # the multi-GPU helper with one rank: the same calls, no collective
+        gpu.render_rgb(52, 36, 8)
+        g = sharded.BinnedGuiding(gpu, (-1, -1, 0), (1, 1, 2))
+        regions, lobes = g.process_batch()
+        g.close()
+        assert len(regions) == 64 and len(lobes) >= 64 and len(gpu.train_samples()) == 0
+    finally:
+        a.close()
+        b.close()
+        L.guiding_set_train_buffer_size(0)
+        gpu.upload_snapshot(np.zeros((0, 8), np.float32), np.zeros((0, 8), np.float32))
+        gpu.render_rgb(44, 28, 1)  # a renderer without a ring for the tests that follow
+
+
 def test_train_sample_ring(gpu):
     """optix_device.cu:431-441 + optix_wrapper.cpp:1270-1294.  Vertices go to hashed ring slots (no shared
     counter in the render's inner loop), so a render with several times more vertices than slots fills
@@ -778,6 +820,20 @@ def test_converged_image_parity(gpu, pipeline):
         sigma = abs(final[..., c].mean() - other[..., c].mean()) / np.sqrt(2) + 1e-4 * ref[..., c].mean() + \
             np.std(final[..., c] - other[..., c]) / np.sqrt(2 * final[..., c].size)
         assert abs(final[..., c].mean() - ref[..., c].mean()) < 3 * sigma + 0.004 * ref[..., c].mean()
+
+
+def test_short_paths_match_the_oracle(gpu, oracle):
+    """max_depth 4 puts the roulette of optix_device.cu:660-672 (last two depths, with the bias of adding
+    radiance x throughput after the division) on bounces that carry energy: image means against the oracle's."""
+    L = gpu.lib()
+    L.pt_set_pipeline(-1)
+    want = np.mean([oracle.render(96, 54, 512, max_depth=4, frame=f)[0].astype(np.float64) for f in (1, 2)], 0)
+    L.pt_set_frame(30)
+    got = [gpu.render_rgb(96, 54, 1024, max_depth=4).astype(np.float64) for _ in range(2)]
+    for c in range(3):
+        sigma = abs(got[0][..., c].mean() - got[1][..., c].mean()) / np.sqrt(2) + 1e-4 * want[..., c].mean()
+        assert abs(0.5 * (got[0][..., c].mean() + got[1][..., c].mean()) - want[..., c].mean()) < 3 * sigma + 0.004 * want[..., c].mean()
+    assert rel_rmse(got[0].astype(np.float32), want.astype(np.float32)) < 0.15
 
 
 def test_bayer_converged_parity(gpu):

@@ -819,3 +819,93 @@ def test_guiding_across_two_ranks(pt, tmp_path):
     r1, l1 = g.process_batch()
     g.close()
     assert len(l1) >= 1 and seen["l"] is l1 and l1[np.argmax(l1[:, 4]), 2] > 0.9
+
+
+# ------------------------------------------------------------------ training statistics binned per region and lobe
+def _random_records(rng, n):
+    rec = np.zeros((n, 10), np.float32)
+    rec[:, 0:2] = rng.uniform(-1.1, 1.1, (n, 2))  # some fall outside the field
+    rec[:, 2] = rng.uniform(-0.1, 2.1, n)
+    d = rng.normal(size=(n, 3))
+    rec[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rec[:, 6:9] = rng.uniform(0, 2, (n, 3)) * (rng.uniform(size=(n, 1)) > 0.05)  # a few with weight zero
+    return rec
+
+
+def test_binned_update_is_the_sample_update(pt):
+    """pgl_field_update fed record by record and pt_pgl_field_update_binned fed the per-(region, lobe) fixed-point
+    sums of the same records (tests/binning.py restates the device kernel) train the same field: twice in a row,
+    so the second batch is assigned by the axes the first one moved."""
+    import binning
+    rng = np.random.default_rng(5)
+    a, b = pt.GuidingField((-1, -1, 0), (1, 1, 2)), pt.GuidingField((-1, -1, 0), (1, 1, 2))
+    try:
+        for _ in range(2):
+            rec = _random_records(rng, 4000)
+            bmin, bmax, res, axes = b.layout()
+            a.update(rec)
+            b.update_binned(binning.bin_records(rec, bmin, bmax, res, axes))
+            (ra, la), (rb, lb) = a.snapshot(), b.snapshot()
+            assert np.array_equal(ra, rb) and la.shape == lb.shape
+            assert np.allclose(la, lb, rtol=2e-5, atol=2e-6), np.abs(la - lb).max()
+            assert np.allclose(a.layout()[3], b.layout()[3], atol=1e-6)  # the assignment axes (2^-24 fixed point against doubles)
+    finally:
+        a.close()
+        b.close()
+
+
+_BINNED_WORKER = r'''
+import sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[5])
+import ptamd, binning
+from ptamd import sharded
+rank = int(sys.argv[3])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=2)
+rng = np.random.default_rng(100 + rank)
+out = []
+g = sharded.BinnedGuiding(ptamd, (-1, -1, 0), (1, 1, 2), upload=lambda r, l: None, reset=lambda: None,
+                          bin=lambda field: torch.from_numpy(binning.bin_records(recs, *field.layout())))
+for batch in range(2):
+    n = 2000 + 700 * rank
+    recs = np.zeros((n, 10), np.float32)
+    recs[:, 0:2] = rng.uniform(-1, 1, (n, 2)); recs[:, 2] = rng.uniform(0, 2, n)
+    d = rng.normal(size=(n, 3)); recs[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    recs[:, 6:9] = rng.uniform(0, 2, (n, 3))
+    regions, lobes = g.process_batch()
+    out.append((recs, regions, lobes))
+g.close()
+np.savez(sys.argv[4] + "/b%d.npz" % rank, **{"%s%d" % (k, i): v for i, t in enumerate(out) for k, v in zip(("rec", "regions", "lobes"), t)})
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_binned_guiding_across_two_ranks(pt, tmp_path):
+    """Every rank keeps a copy of the field and the ranks add their int64 tables with one all-reduce: after two
+    batches both copies are the same bits, and they are the field one process trains on the union of the records."""
+    import socket
+    import binning
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    script = tmp_path / "binned_worker.py"
+    script.write_text(_BINNED_WORKER)
+    pkg = os.path.join(ROOT, "rust-pathtracer_amd")
+    procs = [subprocess.Popen([sys.executable, str(script), pkg, str(port), str(r), str(tmp_path), os.path.join(ROOT, "tests")])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b = (np.load(tmp_path / f"b{r}.npz") for r in range(2))
+    one = pt.GuidingField((-1, -1, 0), (1, 1, 2))
+    try:
+        for i in range(2):
+            assert np.array_equal(a[f"regions{i}"], b[f"regions{i}"]) and np.array_equal(a[f"lobes{i}"], b[f"lobes{i}"])
+            union = np.concatenate([a[f"rec{i}"], b[f"rec{i}"]])
+            one.update_binned(binning.bin_records(union, *one.layout()))
+            regions, lobes = one.snapshot()
+            assert np.array_equal(regions, a[f"regions{i}"]) and np.array_equal(lobes, a[f"lobes{i}"])
+    finally:
+        one.close()
+
