@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 __device__ __forceinline__ uint32_t mix(uint32_t x) {
@@ -40,7 +41,10 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
   uint32_t* out; CK(hipMalloc(&out, 4));
-  const size_t sizes_mb[] = {2, 16, 128, 1152, 8192};
+  // one argument: a single footprint in MB, 7 waves per SIMD, one launch per word count (for counter calibration)
+  const bool single = argc > 1;
+  std::vector<size_t> sizes_mb = {2, 16, 128, 1152, 8192};
+  if (single) sizes_mb = {(size_t)atoll(argv[1])};
   for (size_t mb : sizes_mb) {
     const size_t bytes = mb << 20;
     uint4* p; CK(hipMalloc(&p, bytes));
@@ -48,11 +52,12 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const uint32_t nlines = (uint32_t)(bytes / 128);
     for (int waves : {2, 4, 7, 8}) {           // waves per SIMD: blocks of 256 threads per CU
+      if (single && waves != 7) continue;
       const size_t lds = (160u * 1024u / waves) & ~255u;   // as much LDS as lets exactly `waves` blocks fit
       hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
       for (int words : {5, 8}) {
         float best = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {
+        for (int rep = 0; rep < (single ? 1 : 3); ++rep) {
           CK(hipEventRecord(a));
           if (words == 5) k_chase<5><<<cus * waves, 256, lds>>>(p, nlines, steps, out, 0);
           else k_chase<8><<<cus * waves, 256, lds>>>(p, nlines, steps, out, 0);
@@ -60,8 +65,8 @@ int main(int argc, char** argv) {
           float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
         }
         const double lines = (double)cus * waves * 256 * steps;
-        printf("footprint %5zu MB  %d waves/SIMD  %d x 16 B of each line: %7.3f ms  %6.2f G lines/s  %6.2f TB/s of 128-B lines  (%.0f ns per step per lane)\n",
-               mb, waves, words, best, lines / best / 1e6, lines * 128 / best / 1e9, best * 1e6 / steps);
+        printf("footprint %5zu MB  %d waves/SIMD  %d x 16 B of each line: %7.3f ms  %6.2f G lines/s  %6.2f TB/s of 128-B lines  (%.0f ns per step per lane; %.0f lines = %.1f MB per launch)\n",
+               mb, waves, words, best, lines / best / 1e6, lines * 128 / best / 1e9, best * 1e6 / steps, lines, lines * 128 / 1e6);
       }
     }
     CK(hipFree(p));

@@ -61,6 +61,14 @@ extern __shared__ float g_pad[];
 #define I_CMPCNDM_S(k) "v_cmp_lt_f32 s[22:23], %" #k ", %9\n v_cndmask_b32 %" #k ", %" #k ", %8, s[22:23]\n"
 #define I_CNDM_K(k) "v_cndmask_b32 %" #k ", 0, %" #k ", vcc\n"
 #define I_ADDC(k) "v_addc_co_u32 %" #k ", vcc, %" #k ", %8, vcc\n"
+#define I_FMAMIX(k) "v_fma_mix_f32 %" #k ", %8, %9, %" #k " op_sel_hi:[1,0,0]\n"
+#define I_FMAMIXH(k) "v_fma_mix_f32 %" #k ", %8, %9, %" #k " op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define I_ALIGNBIT(k) "v_alignbit_b32 %" #k ", %" #k ", %8, 31\n"
+#define I_CVTF16(k) "v_cvt_f32_f16 %" #k ", %" #k "\n"
+#define I_PERM(k) "v_perm_b32 %" #k ", %" #k ", %8, %9\n"
+#define I_ANDOR(k) "v_and_or_b32 %" #k ", %" #k ", %8, %9\n"
+#define I_MED3(k) "v_med3_f32 %" #k ", %" #k ", %8, %9\n"
+#define I_OR3(k) "v_or3_b32 %" #k ", %" #k ", %8, %9\n"
 #define I_MBCNT(k) "v_mbcnt_lo_u32_b32 %" #k ", %10, %" #k "\n"
 
 template <int OP>
@@ -98,6 +106,14 @@ __global__ void __launch_bounds__(1024) k_op(float* out, unsigned long long* sta
         if (OP == 41) OP8(I_CMPCNDM_S);
         if (OP == 42) OP8(I_CNDM_K);
         if (OP == 43) OP8(I_ADDC);
+        if (OP == 44) OP8(I_FMAMIX);
+        if (OP == 45) OP8(I_FMAMIXH);
+        if (OP == 46) OP8(I_ALIGNBIT);
+        if (OP == 47) OP8(I_CVTF16);
+        if (OP == 48) OP8(I_PERM);
+        if (OP == 49) OP8(I_ANDOR);
+        if (OP == 50) OP8(I_MED3);
+        if (OP == 51) OP8(I_OR3);
         if (OP == 19) OP8(I_FMA_S);
         if (OP == 20) OP8(I_MUL_S);
         if (OP == 21) OP8(I_MUL_K);
@@ -156,7 +172,10 @@ int main() {
                     {"v_mul_f64", k_op<34>}, {"v_cmp_lt_f32 sgpr", k_op<35>}, {"v_add3_u32", k_op<36>},
                     {"v_pk_fma_f32", k_op<37>}, {"v_pk_mul_f32", k_op<38>},
                     {"v_cndmask e64 vcc", k_op<39>}, {"v_cmp+v_cndmask vcc (2 insts)", k_op<40>},
-                    {"v_cmp+v_cndmask sgpr (2 insts)", k_op<41>}, {"v_cndmask 0,v,vcc", k_op<42>}, {"v_addc_co_u32 vcc", k_op<43>}};
+                    {"v_cmp+v_cndmask sgpr (2 insts)", k_op<41>}, {"v_cndmask 0,v,vcc", k_op<42>}, {"v_addc_co_u32 vcc", k_op<43>},
+                    {"v_fma_mix_f32 f16lo", k_op<44>}, {"v_fma_mix_f32 f16hi", k_op<45>}, {"v_alignbit_b32", k_op<46>},
+                    {"v_cvt_f32_f16", k_op<47>}, {"v_perm_b32", k_op<48>}, {"v_and_or_b32", k_op<49>}, {"v_med3_f32", k_op<50>},
+                    {"v_or3_b32", k_op<51>}};
   struct Mask { const char* name; unsigned long long m; };
   const Mask masks[] = {{"all 64 lanes", ~0ull}, {"lanes 0-31", 0xffffffffull}, {"lanes 32-63", 0xffffffff00000000ull},
                         {"even lanes", 0x5555555555555555ull}, {"lanes 0-15", 0xffffull}, {"lane 0", 1ull}};
