@@ -269,6 +269,33 @@ PT_EXPORT void pt_scene_cornell(void);
 PT_EXPORT void pt_scene_synthetic(uint32_t seed, int n_objects, int subdiv);
 PT_EXPORT int  pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                                   const float* materials11);
+/* Scenes made of instances: meshes in their own object space, each placed any number of times by an affine
+ * transform, under a two-level tree (a top level over the instances' world boxes, one tree per mesh).  The reference's
+ * pipeline allows single-level instancing (optix_wrapper.cpp:565-566) and never uses it; its one acceleration
+ * structure is built over flat triangles (optix_wrapper.cpp:492-544).
+ *   pt_scene_instanced_begin()                        start describing a scene (the reference's light set-up)
+ *   pt_scene_add_mesh(...) -> mesh id                 arrays as for pt_scene_triangles, object space
+ *   pt_scene_add_instance(mesh, xform12, material11)  xform12: object -> world, three rows of (x y z | translation);
+ *                                                     material11 (may be NULL): one material for the whole instance
+ *                                                     in place of the mesh's per-triangle ones; -> instance id
+ *   pt_scene_instanced_commit() -> instances          the described scene becomes the current one
+ * -1 on bad input (nothing changes).  Such scenes render through the staged kernels; hits carry the instance, the
+ * ray is taken to object space with its direction as it is (distances stay the world ray's), normals come back through
+ * the inverse transpose.  pt_scene_flatten() replaces the current scene by its instances written out as world-space
+ * triangles (returns the triangle count); pt_scene_synthetic_instanced is pt_scene_synthetic with the room as one
+ * instance and every sphere an instance of one unit icosphere.  pt_trace_rays_instances is pt_trace_rays that also
+ * returns the instance of each closest hit (-1 for flat scenes or a miss). */
+PT_EXPORT int  pt_scene_instanced_begin(void);
+PT_EXPORT int  pt_scene_add_mesh(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
+                                 const float* materials11);
+PT_EXPORT int  pt_scene_add_instance(int mesh, const float* xform12, const float* material11);
+PT_EXPORT int  pt_scene_instanced_commit(void);
+PT_EXPORT int  pt_scene_flatten(void);
+PT_EXPORT int  pt_scene_instance_count(void);
+PT_EXPORT void pt_scene_synthetic_instanced(uint32_t seed, int n_objects, int subdiv);
+PT_EXPORT int  pt_trace_rays_instances(int n, const float* origins, const float* dirs, const float* tmin, const float* tmax,
+                                       int any_hit, int* out_prim, float* out_t, float* out_b1, float* out_b2,
+                                       int* out_instance);
 /* pgl_samples_add_surface for `count` records in the layout guiding_map_train_samples returns (the host loop
  * of src/guiding.rs:196-219 in one call); used by multi-GPU hosts that gather every rank's ring on one rank. */
 PT_EXPORT void pt_pgl_samples_add_batch(pgl_samples_t samples, const TrainSample* records, uint32_t count);

@@ -425,6 +425,12 @@ struct Emitter {
   void write_tri(uint32_t slot_index, uint32_t item_index) {
     const Item& item = items[(size_t)item_index];
     const uint32_t prim = item.a;
+    if (box_mode) {  // the caller writes the record of box `prim` here once the order is known
+      q4* q = &out.tris[4 * (size_t)slot_index];
+      q[0] = q[2] = q[3] = q4{0.f, 0.f, 0.f, 0.f};
+      q[1] = q4{0.f, 0.f, 0.f, u2f(prim)};
+      return;
+    }
     const uint32_t* t = b.idx + 3 * (size_t)prim;
     double v[3][3];
     for (int k = 0; k < 3; ++k)
@@ -468,6 +474,7 @@ struct Emitter {
   }
   // writes node_index to hn[prim * hn_stride] and the mask to hm[prim * hm_stride]
   void mark_coplanar(uint32_t node_index, uint32_t first, uint32_t count, uint32_t* hn, int hn_stride, uint32_t* hm, int hm_stride) {
+    if (box_mode) return;
     double pl[24][4];
     uint32_t prim[24];
     bool ok[24];
@@ -507,6 +514,8 @@ struct Emitter {
       }
     }
   }
+
+  bool box_mode = false;  // the items are caller-defined boxes, not triangles
 
   // ---- wide nodes for small trees (layout: pt_bvh.h)
   std::vector<float> slot_boxes;  // per node and slot: the child's box, lo xyz hi xyz (filled by emit)
@@ -728,7 +737,17 @@ int g_pairing = -1;  // -1: environment (PT_BVH_PAIRS, default on)
 
 void bvh_set_pairing(int on) { g_pairing = on < 0 ? -1 : (on ? 1 : 0); }
 
+static BvhBuildResult build_common(const float* vertices, const uint32_t* indices, int num_tris, const float* boxes);
+
 BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int num_tris) {
+  return build_common(vertices, indices, num_tris, nullptr);
+}
+BvhBuildResult build_bvh8_boxes(const float* boxes, int num_boxes) {
+  return build_common(nullptr, nullptr, num_boxes, boxes);
+}
+
+// boxes != null: the primitives are boxes (lo xyz, hi xyz each) and the leaf records are left to the caller
+static BvhBuildResult build_common(const float* vertices, const uint32_t* indices, int num_tris, const float* boxes) {
   BvhBuildResult out;
   out.num_tris = num_tris;
   if (num_tris <= 0) {
@@ -744,13 +763,17 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   Builder b;
   b.verts = vertices;
   b.idx = indices;
-  for (size_t k = 0; k < 3 * (size_t)num_tris; ++k) {
-    const float* v = vertices + 3 * (size_t)indices[k];
-    out.vmag = std::max(out.vmag, std::max(std::fabs(v[0]), std::max(std::fabs(v[1]), std::fabs(v[2]))));
+  if (boxes) {
+    for (size_t k = 0; k < 6 * (size_t)num_tris; ++k) out.vmag = std::max(out.vmag, std::fabs(boxes[k]));
+  } else {
+    for (size_t k = 0; k < 3 * (size_t)num_tris; ++k) {
+      const float* v = vertices + 3 * (size_t)indices[k];
+      out.vmag = std::max(out.vmag, std::max(std::fabs(v[0]), std::max(std::fabs(v[1]), std::fabs(v[2]))));
+    }
   }
   // Leaf items: a triangle and its successor in the input become one item when they are the two halves of
   // a parallelogram (how quads arrive in a triangle list); everything else stays a single triangle.
-  const bool pairing = g_pairing >= 0 ? g_pairing != 0 : !(getenv("PT_BVH_PAIRS") && atoi(getenv("PT_BVH_PAIRS")) == 0);
+  const bool pairing = !boxes && (g_pairing >= 0 ? g_pairing != 0 : !(getenv("PT_BVH_PAIRS") && atoi(getenv("PT_BVH_PAIRS")) == 0));
   std::vector<Item> items;
   items.reserve((size_t)num_tris);
   for (int t = 0; t < num_tris; ++t) {
@@ -764,9 +787,14 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   for (int it = 0; it < num_items; ++it) {
     Box bx;
     bx.reset();
-    for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)items[(size_t)it].a + k]);
-    if (items[(size_t)it].b != kNoPartner)
-      for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)items[(size_t)it].b + k]);
+    if (boxes) {
+      bx.grow(boxes + 6 * (size_t)it);
+      bx.grow(boxes + 6 * (size_t)it + 3);
+    } else {
+      for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)items[(size_t)it].a + k]);
+      if (items[(size_t)it].b != kNoPartner)
+        for (int k = 0; k < 3; ++k) bx.grow(vertices + 3 * (size_t)indices[3 * (size_t)items[(size_t)it].b + k]);
+    }
     Builder::Prim& pr = b.prims[(size_t)it];
     for (int k = 0; k < 3; ++k) {
       pr.c[k] = 0.5f * (bx.lo[k] + bx.hi[k]);
@@ -804,10 +832,11 @@ BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int nu
   out.home_mask.assign((size_t)num_tris, 0u);
   out.corner_order.assign((size_t)num_tris, kInputOrder);
   Emitter em{b, out, items};
+  em.box_mode = boxes != nullptr;
   em.below.assign(b.nodes2.size(), 0u);
   const uint32_t nodes_below_root = em.count_below(root2);
   out.nodes.resize(1 + (size_t)nodes_below_root);
-  if (out.nodes.size() <= kWideMaxNodes) em.slot_boxes.assign(48 * out.nodes.size(), 0.0f);
+  if (!boxes && out.nodes.size() <= kWideMaxNodes) em.slot_boxes.assign(48 * out.nodes.size(), 0.0f);
   out.depth = em.emit(0, root2, 1u, 0u);
   if (!em.slot_boxes.empty()) em.build_wide();
   if (timing)

@@ -31,6 +31,9 @@ struct BvhBuildResult {
   int depth = 0;               // levels of internal nodes on the longest root-to-leaf path
   int num_tris = 0;
   int num_items = 0;           // leaf items: single triangles, or two triangles forming a parallelogram
+  // Instanced scenes only (renderer.cpp: build_instanced): 6 q4 per instance for shading -- rows of the world ->
+  // object matrix, then the instance's own material if it has one (pt_types.h: SceneView::inst_records)
+  std::vector<q4> inst_records;
 };
 
 constexpr size_t kWideMaxNodes = 96;
@@ -41,5 +44,9 @@ void bvh_set_pairing(int on);
 
 // vertices: 3 floats each; indices: 3 per triangle.
 BvhBuildResult build_bvh8(const float* vertices, const uint32_t* indices, int num_tris);
+// The same tree over caller-defined boxes (6 floats each: lo xyz, hi xyz), for the top level of an instanced scene.
+// Every box is one leaf item; its record in `tris` holds the box index in the w of its second word and zeros
+// elsewhere, for the caller to fill in.  No pairing, no origin-plane table, no wide form.
+BvhBuildResult build_bvh8_boxes(const float* boxes, int num_boxes);
 
 }  // namespace pt

@@ -420,7 +420,28 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
 // whose ray has finished takes the next ray while its neighbours are still traversing theirs.
 // A ray is in one of three states: triangles of a visited node wait to be tested (wants_tri), child
 // nodes wait to be visited (wants_node), or nothing is left (done).
-struct TraceState {
+//
+// INST: the scene is a top-level tree over instances of meshes (SceneView::inst_records).  A leaf item of the
+// top level is an instance record,
+//   q0..q2 = rows of the world -> object matrix (xyz | translation)
+//   q3     = root node of the mesh's tree, instance index, largest |coordinate| of the mesh, 0
+// and testing it means entering the instance: what is left of the top-level node goes on the stack, the ray is
+// taken to object space (direction not renormalised, so distances along the ray stay the same numbers) and the
+// mesh's tree is walked with it; when the stack is back to where it was, the world ray resumes.  Rays get no
+// origin-plane hint in such scenes.
+constexpr uint32_t kNoInstance = 0xffffffffu;
+template <bool INST>
+struct InstancePart {};
+template <>
+struct InstancePart<true> {
+  f3 oo, od;          // the ray in the space of the instance it is in
+  uint32_t inst;      // that instance, kNoInstance at the top level
+  uint32_t hit_inst;  // the instance of the closest hit so far
+  int ret_sp;         // stack level at which the instance was entered
+};
+
+template <bool INST>
+struct TraceStateT : InstancePart<INST> {
   // the ray itself (origin, direction, tmin) stays with the caller and is passed to every step
   f3 idir;
   uint32_t octinv;
@@ -430,31 +451,57 @@ struct TraceState {
   int sp;
   uint32_t home_node, home_mask;
 
+  PT_HD void set_ray(f3 o, f3 d, float vmag) {
+    idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+    rmag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + vmag;
+  }
   PT_HD void begin(const SceneView& sc, f3 o, f3 d, float tmax, uint32_t origin) {
     hit = Hit{-1, tmax, 0.f, 0.f};
     home_node = 0xffffffffu;
     home_mask = 0u;
-    if (origin) {
+    if (!INST && origin) {
       const ShadeRec* rec = sc.shade + (origin - 1u);
       home_node = rec->home_node;
       home_mask = rec->home_mask;
     }
-    idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
-    rmag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.vmag;
+    set_ray(o, d, sc.vmag);
     cur = StackEntry{0u, 0x80000000u};
     tg = StackEntry{0u, 0u};
     sp = 0;
+    if constexpr (INST) {
+      this->inst = kNoInstance;
+      this->hit_inst = kNoInstance;
+      this->ret_sp = 0;
+      this->oo = o;
+      this->od = d;
+    }
   }
   PT_HD bool wants_tri() const { return tg.bits != 0u; }
   PT_HD bool wants_node() const { return tg.bits == 0u && (cur.bits != 0u || sp > 0); }  // cur.bits != 0: children left
   PT_HD bool done() const { return tg.bits == 0u && cur.bits == 0u && sp == 0; }
   PT_HD void finish() { tg.bits = 0u; cur.bits = 0u; sp = 0; }
 
-  // visit one child node
+  // visit one child node (o, d: the world ray)
   template <class Stack>
-  PT_HD void node_step(const SceneView& sc, f3 o, float tmin, Stack& stack, int stack_limit) {
-    if (cur.bits == 0u) cur = stack.pop(--sp);  // only entries with children left to visit are ever pushed
+  PT_HD void node_step(const SceneView& sc, f3 o, f3 d, float tmin, Stack& stack, int stack_limit) {
+    if (cur.bits == 0u) {
+      if constexpr (INST) {
+        if (this->inst != kNoInstance && sp == this->ret_sp) {  // the mesh's tree is done: back to the world ray
+          this->inst = kNoInstance;
+          set_ray(o, d, sc.vmag);
+          if (sp == 0) return;
+        }
+      }
+      cur = stack.pop(--sp);  // only entries with something left to visit are ever pushed
+      if constexpr (INST) {
+        if ((cur.bits & 0xff000000u) == 0u) {  // instance records of a top-level node that were set aside
+          tg = cur;
+          cur.bits = 0u;
+          return;
+        }
+      }
+    }
     const uint32_t hits_imask = cur.bits;
     const int bit = 31 - __builtin_clz(hits_imask);
     cur.bits &= ~(1u << bit);
@@ -465,6 +512,9 @@ struct TraceState {
     const NodeWords n = load_node(sc.nodes, node_index);
     RayBox rb;
     rb.o = o;
+    if constexpr (INST) {
+      if (this->inst != kNoInstance) rb.o = this->oo;
+    }
     rb.idir = idir;
     rb.octinv = octinv;
     const uint32_t hm = intersect_children(n, rb, tmin, hit.t);
@@ -476,8 +526,9 @@ struct TraceState {
     if (node_index == home_node) tg.bits &= ~home_mask;
   }
 
-  // test one waiting triangle; returns true when an any-hit ray has found its occluder
-  PT_HD bool tri_step(const SceneView& sc, f3 o, f3 d, float tmin, bool any_hit) {
+  // test one waiting leaf item; returns true when an any-hit ray has found its occluder
+  template <class Stack>
+  PT_HD bool tri_step(const SceneView& sc, f3 o, f3 d, float tmin, bool any_hit, Stack& stack, int stack_limit) {
     const int ti = __builtin_ctz(tg.bits);
     tg.bits &= tg.bits - 1u;
     const q4* tp = sc.tris + (uint32_t)kTriWords * (tg.base + (uint32_t)ti);
@@ -487,10 +538,32 @@ struct TraceState {
     // sinks the loads of the two barycentric rows behind the plane-distance test, a second dependent miss per item.
     asm volatile("" ::"v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w));
 #endif
-    int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, tmin, hit);
-    if (res == 2) res = watertight_item(sc, q1, q2, q3, o, d, tmin, hit) ? 1 : 0;
-    return res == 1 && any_hit;
+    if constexpr (INST) {
+      if (this->inst == kNoInstance) {  // an instance record: enter it
+        if (tg.bits && sp < stack_limit) stack.push(sp++, StackEntry{tg.base, tg.bits});
+        if ((cur.bits & 0xff000000u) && sp < stack_limit) stack.push(sp++, cur);
+        this->ret_sp = sp;
+        this->inst = f2u(q3.y);
+        this->oo = mk3(q0.x * o.x + q0.y * o.y + q0.z * o.z + q0.w, q1.x * o.x + q1.y * o.y + q1.z * o.z + q1.w,
+                       q2.x * o.x + q2.y * o.y + q2.z * o.z + q2.w);
+        this->od = mk3(q0.x * d.x + q0.y * d.y + q0.z * d.z, q1.x * d.x + q1.y * d.y + q1.z * d.z,
+                       q2.x * d.x + q2.y * d.y + q2.z * d.z);
+        set_ray(this->oo, this->od, q3.z);
+        cur = StackEntry{f2u(q3.x), 0x80000000u};
+        tg.bits = 0u;
+        return false;
+      }
+      int res = fast_triangle(q0, q1, q2, q3, this->oo, this->od, rmag, tmin, hit);
+      if (res == 2) res = watertight_item(sc, q1, q2, q3, this->oo, this->od, tmin, hit) ? 1 : 0;
+      if (res == 1) this->hit_inst = this->inst;
+      return res == 1 && any_hit;
+    } else {
+      int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, tmin, hit);
+      if (res == 2) res = watertight_item(sc, q1, q2, q3, o, d, tmin, hit) ? 1 : 0;
+      return res == 1 && any_hit;
+    }
   }
 };
+using TraceState = TraceStateT<false>;
 
 }  // namespace pt

@@ -41,6 +41,7 @@ struct RenderParams {
   uint32_t* counters;      // CNT_WORDS words
   unsigned long long* ray_counters;  // [0] radiance rays, [1] shadow rays
   q4* hits;                // per queue slot: prim bits, t, b1, b2
+  uint32_t* hit_inst;      // per queue slot: the instance the hit primitive belongs to (instanced scenes)
   q4* sh_o;                // shadow queue: origin.xyz, tmax
   q4* sh_d;                //               dir.xyz, pixel bits
   q4* sh_c;                //               contrib.xyz
@@ -115,7 +116,7 @@ void launch_dbg_pcg(unsigned long long seed, int n, uint32_t* out_u, float* out_
 void launch_dbg_blue_noise(int n, const int* xysf, float* uv, float* jitter, hipStream_t s);
 void launch_dbg_camera(CameraView cam, int w, int h, int n, const int* xy, const float* jitter, float* dirs, hipStream_t s);
 void launch_trace_rays(SceneView sc, int stack_depth, int n, const float* o, const float* d, const float* tmin,
-                       const float* tmax, int any_hit, int* prim, float* t, float* b1, float* b2, hipStream_t s);
+                       const float* tmax, int any_hit, int* prim, float* t, float* b1, float* b2, int* inst, hipStream_t s);
 struct DbgPathRec {  // == pt_path_rec in include/pt_api.h
   float radiance[3]; float throughput[3]; float origin[3]; float direction[3];
   unsigned long long seed; int depth; int done; float prev_pdf_bsdf; int prev_pdf_valid;

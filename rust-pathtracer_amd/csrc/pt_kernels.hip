@@ -270,6 +270,8 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
 // their rays they take the next ones from the range while the rest keep traversing.  Each iteration
 // advances every busy lane by one step: a child-node visit or a triangle test.
 
+// INST: the scene is made of instances (pt_bvh.h: TraceStateT<true>); the hit's instance goes to hit_inst.
+template <bool INST>
 __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
   const uint32_t n = p.counters[q];
   const uint32_t* queue = p.queue[q];
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
   const uint32_t per = (n + nwaves - 1u) / nwaves;
   uint32_t cursor = wave * per;  // the same on every lane
   const uint32_t end = cursor + per < n ? cursor + per : n;
-  TraceState ts;
+  TraceStateT<INST> ts;
   ts.finish();
   f3 ro = mk3(0.f), rd = mk3(0.f);
   uint32_t idx = 0xffffffffu;  // queue position of the lane's ray, none yet
@@ -307,14 +309,15 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
     if (idx != 0xffffffffu) { PT_PROF(PF_BOUNCE); }
     if (idx != 0xffffffffu && ts.wants_node()) {
       PT_PROF(PF_NODE);
-      ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
+      ts.node_step(p.scene, ro, rd, 0.0f, st, p.stack_depth);
     }
     if (idx != 0xffffffffu && ts.wants_tri()) {
       PT_PROF(PF_TRI);
-      ts.tri_step(p.scene, ro, rd, 0.0f, false);
+      ts.tri_step(p.scene, ro, rd, 0.0f, false, st, p.stack_depth);
     }
     if (idx != 0xffffffffu && ts.done()) {
       p.hits[idx] = q4{u2f((uint32_t)ts.hit.prim), ts.hit.t, ts.hit.b1, ts.hit.b2};
+      if constexpr (INST) p.hit_inst[idx] = ts.hit_inst;
       idx = 0xffffffffu;
     }
   }
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
 }
 
 // ---------------------------------------------------------------------------- shade
-template <bool GUIDED, bool TRAIN>
+template <bool GUIDED, bool TRAIN, bool INST>
 __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
   const uint32_t n = p.counters[q];
   const uint32_t* queue = p.queue[q];
@@ -345,7 +348,8 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       const Slot sl = decode_slot(p, pixel);
       RandCtx rc = make_rand_ctx(sl.x, sl.y, 0, p.frame);
       rc.s = ps_dim(ps) < 2u ? hash_sample_index(p, sl, p.started[pixel] - 1) : 0;
-      shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
+      if constexpr (INST) shade_hit_instanced<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, p.hit_inst[i], sr, tv);
+      else shade_hit<GUIDED, TRAIN>(p.scene, p.guide, sp, rc, ps, h, sr, tv);
       seed_after = ps.seed;
       store_state(p, pixel, ps);
     }
@@ -366,6 +370,7 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
 }
 
 // -------------------------------------------------------------------------- occlude
+template <bool INST>
 __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   const uint32_t n = p.counters[q];
   LdsStack st = lds_stack();
@@ -376,7 +381,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   uint32_t cursor = wave * per;
   const uint32_t end = cursor + per < n ? cursor + per : n;
   uint32_t traced = 0;
-  TraceState ts;
+  TraceStateT<INST> ts;
   ts.finish();
   f3 ro = mk3(0.f), rd = mk3(0.f);
   uint32_t idx = 0xffffffffu;
@@ -406,11 +411,11 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
     if (idx != 0xffffffffu) { PT_PROF(PF_SHADOW); }
     if (idx != 0xffffffffu && ts.wants_node()) {
       PT_PROF(PF_SH_NODE);
-      ts.node_step(p.scene, ro, 0.0f, st, p.stack_depth);
+      ts.node_step(p.scene, ro, rd, 0.0f, st, p.stack_depth);
     }
     if (idx != 0xffffffffu && ts.wants_tri()) {
       PT_PROF(PF_SH_TRI);
-      if (ts.tri_step(p.scene, ro, rd, 0.0f, true)) ts.finish();
+      if (ts.tri_step(p.scene, ro, rd, 0.0f, true, st, p.stack_depth)) ts.finish();
     }
     if (idx != 0xffffffffu && ts.done()) {
       if (ts.hit.prim < 0) {
@@ -913,14 +918,16 @@ void launch_generate(const RenderParams& p, int qin, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_extend(const RenderParams& p, int q, const LaunchCfg& c) {
-  k_extend<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
+  if (p.scene.inst_records) k_extend<true><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
+  else k_extend<false><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
   PT_KCHECK();
 }
 // GUIDED and TRAIN are compiled in separately: a guided render without a training ring (or the other way round)
 // does not carry the other's registers.
 template <bool GUIDED, bool TRAIN>
 static void launch_shade_t(const RenderParams& p, int q, const LaunchCfg& c) {
-  k_shade<GUIDED, TRAIN><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
+  if (p.scene.inst_records) k_shade<GUIDED, TRAIN, true><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
+  else k_shade<GUIDED, TRAIN, false><<<c.blocks, c.threads, 0, c.stream>>>(p, q);
 }
 void launch_shade(const RenderParams& p, int q, const LaunchCfg& c) {
   const bool g = p.guiding != 0, t = p.train != nullptr;
@@ -931,7 +938,8 @@ void launch_shade(const RenderParams& p, int q, const LaunchCfg& c) {
   PT_KCHECK();
 }
 void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c) {
-  k_occlude<<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
+  if (p.scene.inst_records) k_occlude<true><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
+  else k_occlude<false><<<c.blocks, c.threads, stack_bytes(p, c), c.stream>>>(p, q);
   PT_KCHECK();
 }
 template <bool GUIDED, bool TRAIN>
@@ -1047,11 +1055,24 @@ __global__ void k_dbg_camera(CameraView cam, int w, int h, int n, const int* xy,
 }
 __global__ void __launch_bounds__(256) k_trace_rays(SceneView sc, int stack_depth, int n, const float* o, const float* d,
                                                     const float* tmin, const float* tmax, int any_hit, int* prim,
-                                                    float* t, float* b1, float* b2) {
+                                                    float* t, float* b1, float* b2, int* inst) {
   LdsStack st = lds_stack();
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const Hit h = trace_ray(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
-                            tmin[i], tmax[i], any_hit != 0, st, stack_depth);
+    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    Hit h;
+    if (sc.inst_records) {  // instanced scenes are walked step by step, as the staged kernels walk them
+      TraceStateT<true> ts;
+      ts.begin(sc, ro, rd, tmax[i], 0u);
+      while (!ts.done()) {
+        if (ts.wants_node()) ts.node_step(sc, ro, rd, tmin[i], st, stack_depth);
+        if (ts.wants_tri() && ts.tri_step(sc, ro, rd, tmin[i], any_hit != 0, st, stack_depth)) ts.finish();
+      }
+      h = ts.hit;
+      if (inst) inst[i] = (int)ts.hit_inst;
+    } else {
+      h = trace_ray(sc, ro, rd, tmin[i], tmax[i], any_hit != 0, st, stack_depth);
+      if (inst) inst[i] = -1;
+    }
     if (any_hit) {
       prim[i] = h.prim >= 0 ? 1 : 0;
     } else {
@@ -1144,9 +1165,9 @@ static int blocks_for(int n) {
   return b < 1 ? 1 : (b > 2048 ? 2048 : b);
 }
 void launch_trace_rays(SceneView sc, int stack_depth, int n, const float* o, const float* d, const float* tmin,
-                       const float* tmax, int any_hit, int* prim, float* t, float* b1, float* b2, hipStream_t s) {
+                       const float* tmax, int any_hit, int* prim, float* t, float* b1, float* b2, int* inst, hipStream_t s) {
   const size_t lds = 256 * (size_t)(stack_depth > 0 ? stack_depth : 1) * sizeof(StackEntry);
-  k_trace_rays<<<blocks_for(n), 256, lds, s>>>(sc, stack_depth, n, o, d, tmin, tmax, any_hit, prim, t, b1, b2);
+  k_trace_rays<<<blocks_for(n), 256, lds, s>>>(sc, stack_depth, n, o, d, tmin, tmax, any_hit, prim, t, b1, b2, inst);
   PT_KCHECK();
 }
 void launch_dbg_shade(SceneView sc, GuideView gv, int guiding, int stack_depth, int n, DbgPathRec* recs, const int* prim,

@@ -128,30 +128,56 @@ struct TrainVertex {
   f3 P, dir_in, T_in;
 };
 
-// One bounce.  hit.prim < 0 is the radiance miss (optix_device.cu:370-375).
-// GUIDED compiles the guided diffuse branch in (used when a field snapshot is active);
-// TRAIN fills `tv` for the caller to append to the training ring.
-template <bool GUIDED, bool TRAIN>
-PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams& sp, const RandCtx& rc,
-                     PathState& ps, const Hit& hit, ShadowRay& sr, TrainVertex& tv) {
-  sr.valid = false;
-  sr.origin = 0u;
-  ps.origin = 0u;
-  if (TRAIN) tv.valid = false;
-  if (hit.prim < 0) {
-    ps.flags &= ~kAlive;  // radiance = 0, done = 1: nothing to add
-    return;
-  }
-  PT_PROF(PF_SHADE);
-  // optix_device.cu:404-429: geometry and material of the primitive
+// The point a path has arrived at (optix_device.cu:404-429): position, geometric normal and material.
+// origin_hint: 1 + the primitive, for the origin-plane skip of the rays that leave it (0: no hint).
+struct Surface {
+  f3 P, Ng, Base_colour, Emission;
+  float Roughness, IOR, Transmission;
+  uint32_t origin_hint;
+};
+PT_HD Surface load_surface(const SceneView& sc, const Hit& hit) {
   const q4* rec = reinterpret_cast<const q4*>(sc.shade + hit.prim);
   const q4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5];
   const f3 v0 = ldv(r0), v1 = ldv(r1), v2 = ldv(r2);
-  const float Roughness = r0.w, IOR = r1.w, Transmission = r2.w;
   const float b1 = hit.b1, b2 = hit.b2, b0 = 1.0f - b1 - b2;
-  const f3 P = v0 * b0 + v1 * b1 + v2 * b2;
-  const f3 Ng = ldv(r3);
-  const f3 Base_colour = ldv(r4), Emission = ldv(r5);
+  Surface sf;
+  sf.P = v0 * b0 + v1 * b1 + v2 * b2;
+  sf.Ng = ldv(r3);
+  sf.Base_colour = ldv(r4);
+  sf.Emission = ldv(r5);
+  sf.Roughness = r0.w;
+  sf.IOR = r1.w;
+  sf.Transmission = r2.w;
+  sf.origin_hint = (uint32_t)hit.prim + 1u;
+  return sf;
+}
+// The same for a hit inside an instance (records: 6 q4 per instance, rows of the world -> object matrix, then an
+// optional material).  The mesh's record is in object space: the point is taken on the world ray, the normal goes
+// through the transpose of world -> object, and a ray that leaves gets no origin hint (the hint names a node of the
+// mesh's tree, which other instances share).
+PT_HD Surface load_surface_instanced(const SceneView& sc, const Hit& hit, uint32_t inst, f3 o, f3 d) {
+  Surface sf = load_surface(sc, hit);
+  const q4* x = sc.inst_records + 6u * inst;
+  const q4 w0 = x[0], w1 = x[1], w2 = x[2], m0 = x[3], m1 = x[4], m2 = x[5];
+  sf.P = o + d * hit.t;
+  const f3 n = sf.Ng;
+  sf.Ng = normalize3(mk3(w0.x * n.x + w1.x * n.y + w2.x * n.z, w0.y * n.x + w1.y * n.y + w2.y * n.z,
+                         w0.z * n.x + w1.z * n.y + w2.z * n.z));
+  if (m2.y != 0.0f) {  // the instance brings its own material
+    sf.Base_colour = mk3(m0.x, m0.y, m0.z); sf.Roughness = m0.w;
+    sf.Emission = mk3(m1.x, m1.y, m1.z); sf.IOR = m1.w;
+    sf.Transmission = m2.x;
+  }
+  sf.origin_hint = 0u;
+  return sf;
+}
+
+template <bool GUIDED, bool TRAIN>
+PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadeParams& sp, const RandCtx& rc,
+                         PathState& ps, const Surface& sf, ShadowRay& sr, TrainVertex& tv) {
+  PT_PROF(PF_SHADE);
+  const f3 P = sf.P, Ng = sf.Ng, Base_colour = sf.Base_colour, Emission = sf.Emission;
+  const float Roughness = sf.Roughness, IOR = sf.IOR, Transmission = sf.Transmission;
   const f3 dir = ps.d;
 
   const bool is_delta = (Transmission > 0.0f) || (Roughness <= 0.0f);
@@ -250,7 +276,7 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
         const f3 contrib = ld3(sc.light_emit) * f * (cosS * cosL * rcp(dist2)) * area;
         Lo = contrib * w;
         sr.valid = true;
-        sr.origin = (uint32_t)hit.prim + 1u;
+        sr.origin = sf.origin_hint;
         sr.o = P + Ng * 1e-3f;
         sr.d = wi;
         sr.tmax = dist - 1e-3f;
@@ -357,13 +383,44 @@ PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams
   }
 
   // the new ray leaves this primitive's plane if it points to the side its origin was pushed to
-  if (dot(ps.d, ps.o - P) > 0.0f) ps.origin = (uint32_t)hit.prim + 1u;
+  if (dot(ps.d, ps.o - P) > 0.0f) ps.origin = sf.origin_hint;
 
   if (!depth_and_roulette(ps, rc, sp.max_depth)) ps.flags &= ~kAlive;
 
   // optix_device.cu:988-989: contribution = radiance * throughput (post-bounce)
   ps.sum += radiance * ps.T;
   if (sr.valid) sr.contrib = sr.contrib * ps.T;
+}
+
+// One bounce.  hit.prim < 0 is the radiance miss (optix_device.cu:370-375).
+// GUIDED compiles the guided diffuse branch in (used when a field snapshot is active);
+// TRAIN fills `tv` for the caller to append to the training ring.
+template <bool GUIDED, bool TRAIN>
+PT_HD void shade_hit(const SceneView& sc, const GuideView& gv, const ShadeParams& sp, const RandCtx& rc,
+                     PathState& ps, const Hit& hit, ShadowRay& sr, TrainVertex& tv) {
+  sr.valid = false;
+  sr.origin = 0u;
+  ps.origin = 0u;
+  if (TRAIN) tv.valid = false;
+  if (hit.prim < 0) {
+    ps.flags &= ~kAlive;  // radiance = 0, done = 1: nothing to add
+    return;
+  }
+  shade_surface<GUIDED, TRAIN>(sc, gv, sp, rc, ps, load_surface(sc, hit), sr, tv);
+}
+// ... of a scene made of instances: `inst` is the instance the hit primitive belongs to
+template <bool GUIDED, bool TRAIN>
+PT_HD void shade_hit_instanced(const SceneView& sc, const GuideView& gv, const ShadeParams& sp, const RandCtx& rc,
+                               PathState& ps, const Hit& hit, uint32_t inst, ShadowRay& sr, TrainVertex& tv) {
+  sr.valid = false;
+  sr.origin = 0u;
+  ps.origin = 0u;
+  if (TRAIN) tv.valid = false;
+  if (hit.prim < 0) {
+    ps.flags &= ~kAlive;
+    return;
+  }
+  shade_surface<GUIDED, TRAIN>(sc, gv, sp, rc, ps, load_surface_instanced(sc, hit, inst, ps.o, ps.d), sr, tv);
 }
 
 // optix_device.cu:955-969: start sample `s` of pixel (x,y).  The caller supplies the PCG

@@ -272,6 +272,10 @@ struct SceneView {
   // from the plane
   const q4* tris;
   const ShadeRec* shade;     // per primitive
+  // Scenes made of instances (else null): 6 q4 per instance -- rows of the world -> object matrix, then an optional
+  // material (base rgb, roughness | emission rgb, ior | transmission, present flag).  The top-level tree's leaf items
+  // are instance records (pt_bvh.h) and the meshes' trees follow it in `nodes`; primitives are in object space.
+  const q4* inst_records;
   uint32_t num_tris;         // primitives (shade records)
   uint32_t num_items;        // traversal records
   float vmag;                // largest |coordinate| of any vertex (error bound of the fast triangle test)

@@ -138,7 +138,8 @@ uint64_t g_bvh_version = 0;
 const BvhBuildResult& current_bvh() {
   HostScene& hs = scene();
   if (g_bvh_version != g_scene_version) {
-    g_bvh = build_bvh8(hs.vertices.data(), hs.indices.data(), hs.num_tris());
+    if (hs.instanced()) g_bvh = build_instanced(hs);
+    else g_bvh = build_bvh8(hs.vertices.data(), hs.indices.data(), hs.num_tris());
     g_bvh_version = g_scene_version;
   }
   return g_bvh;
@@ -202,6 +203,8 @@ void upload_scene(State& s) {
   upload(s.d_shade, recs);
   upload(s.d_wide, bvh.wide_nodes);
   upload(s.d_home_wide, bvh.home_wide);
+  upload(s.d_inst, bvh.inst_records);
+  s.scene.inst_records = bvh.inst_records.empty() ? nullptr : s.d_inst;
   s.scene.wide = nullptr;
   s.scene.wide_src = bvh.wide_nodes.empty() ? nullptr : s.d_wide;
   s.scene.home_wide = bvh.wide_nodes.empty() ? nullptr : s.d_home_wide;
@@ -302,6 +305,7 @@ State* make_state(int W, int H, int device = -1) {
   s->st_m = dev_alloc<u4>(slots); s->acc = dev_alloc<q4>(slots); s->hits = dev_alloc<q4>(slots);
   s->sh_o = dev_alloc<q4>(slots); s->sh_d = dev_alloc<q4>(slots); s->sh_c = dev_alloc<q4>(slots);
   s->started = dev_alloc<int>(slots);
+  s->hit_inst = dev_alloc<uint32_t>(slots);
   s->queue[0] = dev_alloc<uint32_t>(slots);
   s->queue[1] = dev_alloc<uint32_t>(slots);
   s->counters = dev_alloc<uint32_t>(CNT_WORDS);
@@ -419,6 +423,7 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   p.counters = s.counters;
   p.ray_counters = s.ray_counters;
   p.hits = s.hits;
+  p.hit_inst = s.hit_inst;
   p.sh_o = s.sh_o; p.sh_d = s.sh_d; p.sh_c = s.sh_c;
   // optix_device.cu:432: training records are captured whenever the ring exists
   p.train = s.d_train;
@@ -460,6 +465,10 @@ struct RenderLoop {
     // launch overhead; the fused kernel then finishes the stragglers, many bounces per launch.  Both
     // pipelines work on the same state and give the same bits.
     tail_fused = chosen < 0 && !fused;
+    if (s.scene.inst_records) {  // instances are walked by the staged traversal kernels only
+      fused = false;
+      tail_fused = false;
+    }
     if (s.borrowed) {  // no hit / shadow records exist: the fused kernels only
       fused = true;
       tail_fused = false;
@@ -869,7 +878,7 @@ State::~State() {
   for (TimedLaunch& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade); dev_free(d_wide); dev_free(d_home_wide);
   dev_free(st_o); dev_free(st_d); dev_free(st_s); dev_free(st_m); dev_free(acc); dev_free(hits);
-  dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started);
+  dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started); dev_free(hit_inst); dev_free(d_inst);
   dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);
@@ -1135,6 +1144,11 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
                     "(use pt_render_accumulate_device, or guiding_set_enabled(0))\n");
     return -2;
   }
+  if (scene().instanced()) {
+    fprintf(stderr, "[pt_hip] pt_render_accumulate_device_noalloc: scenes made of instances need the staged kernels' hit "
+                    "records (use pt_render_accumulate_device)\n");
+    return -2;
+  }
   // scene: small scenes only, copied into the array when the scene has changed
   const BvhBuildResult& bvh = current_bvh();
   const size_t nodes_b = (bvh.nodes.size() * sizeof(BvhNode) + 255u) & ~(size_t)255u;
@@ -1168,6 +1182,7 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
     s.scene.nodes = dn;
     s.scene.tris = dt;
     s.scene.shade = ds;
+    s.scene.inst_records = nullptr;
     describe_scene(s, bvh);
   }
   s.width = w;
@@ -1352,6 +1367,92 @@ int pt_scene_triangles(const float* vertices, int n_vertices, const uint32_t* in
   g_scene_version++;
   return 0;
 }
+// ---- scenes made of instances (include/pt_api.h)
+static HostScene g_pending;      // the instanced scene being described
+static bool g_pending_open = false;
+int pt_scene_instanced_begin(void) {
+  g_pending = make_from_triangles(nullptr, 0, nullptr, 0, nullptr);  // empty geometry, the reference's light
+  g_pending_open = true;
+  return 0;
+}
+int pt_scene_add_mesh(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles, const float* materials11) {
+  const char* why = nullptr;
+  if (!g_pending_open) why = "no instanced scene has been begun";
+  else if (n_vertices <= 0 || n_triangles <= 0) why = "empty mesh";
+  else if (!vertices || !indices) why = "null array";
+  for (size_t k = 0; !why && k < 3 * (size_t)n_triangles; ++k)
+    if (indices[k] >= (uint32_t)n_vertices) why = "vertex index out of range";
+  for (size_t k = 0; !why && k < 3 * (size_t)n_vertices; ++k)
+    if (!std::isfinite(vertices[k])) why = "vertex coordinate not finite";
+  for (size_t k = 0; !why && materials11 && k < 11 * (size_t)n_triangles; ++k)
+    if (!std::isfinite(materials11[k])) why = "material value not finite";
+  if (why) {
+    fprintf(stderr, "[pt_hip] pt_scene_add_mesh: %s\n", why);
+    return -1;
+  }
+  const HostScene one = make_from_triangles(vertices, n_vertices, indices, n_triangles, materials11);
+  const uint32_t vbase = (uint32_t)(g_pending.vertices.size() / 3);
+  HostScene::MeshRange mr{(uint32_t)g_pending.num_tris(), (uint32_t)n_triangles};
+  g_pending.vertices.insert(g_pending.vertices.end(), one.vertices.begin(), one.vertices.end());
+  for (uint32_t i : one.indices) g_pending.indices.push_back(vbase + i);
+  g_pending.materials.insert(g_pending.materials.end(), one.materials.begin(), one.materials.end());
+  g_pending.meshes.push_back(mr);
+  return (int)g_pending.meshes.size() - 1;
+}
+int pt_scene_add_instance(int mesh, const float* xform12, const float* material11) {
+  const char* why = nullptr;
+  double inv[12];
+  if (!g_pending_open) why = "no instanced scene has been begun";
+  else if (mesh < 0 || (size_t)mesh >= g_pending.meshes.size()) why = "no such mesh";
+  else if (!xform12) why = "null transform";
+  for (int k = 0; !why && k < 12; ++k)
+    if (!std::isfinite(xform12[k])) why = "transform not finite";
+  for (int k = 0; !why && material11 && k < 11; ++k)
+    if (!std::isfinite(material11[k])) why = "material value not finite";
+  if (!why && !invert_affine(xform12, inv)) why = "transform cannot be inverted";
+  if (why) {
+    fprintf(stderr, "[pt_hip] pt_scene_add_instance: %s\n", why);
+    return -1;
+  }
+  HostScene::Instance in{};
+  in.mesh = (uint32_t)mesh;
+  memcpy(in.xform, xform12, sizeof(in.xform));
+  if (material11) {
+    in.has_material = 1;
+    memcpy(&in.material, material11, sizeof(Material));
+  }
+  g_pending.instances.push_back(in);
+  return (int)g_pending.instances.size() - 1;
+}
+int pt_scene_instanced_commit(void) {
+  if (!g_pending_open || g_pending.instances.empty()) {
+    fprintf(stderr, "[pt_hip] pt_scene_instanced_commit: no instances; the current scene is kept\n");
+    return -1;
+  }
+  g_pending.compute_normals();
+  g_scene = std::move(g_pending);
+  g_pending = HostScene();
+  g_pending_open = false;
+  g_scene_init = true;
+  g_scene_version++;
+  return (int)g_scene.instances.size();
+}
+void pt_scene_synthetic_instanced(uint32_t seed, int n_objects, int subdiv) {
+  g_scene = make_synthetic_instanced(seed, n_objects, subdiv);
+  g_scene_init = true;
+  g_scene_version++;
+}
+// The current scene's instances written out as world-space triangles become the scene (a flat scene stays as it is).
+int pt_scene_flatten(void) {
+  HostScene& hs = scene();
+  if (hs.instanced()) {
+    g_scene = hs.flattened();
+    g_scene_version++;
+  }
+  return g_scene.num_tris();
+}
+int pt_scene_instance_count(void) { return (int)scene().instances.size(); }
+
 void pt_scene_counts(int* n_vertices, int* n_triangles) {
   HostScene& hs = scene();
   if (n_vertices) *n_vertices = (int)(hs.vertices.size() / 3);
@@ -1439,15 +1540,21 @@ int pt_dbg_camera_dirs(int w, int h, int n, const int* xy, const float* jitter, 
 }
 int pt_trace_rays(int n, const float* origins, const float* dirs, const float* tmin, const float* tmax, int any_hit,
                   int* out_prim, float* out_t, float* out_b1, float* out_b2) {
+  return pt_trace_rays_instances(n, origins, dirs, tmin, tmax, any_hit, out_prim, out_t, out_b1, out_b2, nullptr);
+}
+int pt_trace_rays_instances(int n, const float* origins, const float* dirs, const float* tmin, const float* tmax, int any_hit,
+                            int* out_prim, float* out_t, float* out_b1, float* out_b2, int* out_instance) {
   State& s = dbg_state();
+  DevBuf<int> inst((size_t)n);
   DevBuf<float> o(origins, (size_t)n * 3), d(dirs, (size_t)n * 3), t0(tmin, (size_t)n), t1(tmax, (size_t)n);
   DevBuf<int> prim((size_t)n);
   DevBuf<float> t((size_t)n), b1((size_t)n), b2((size_t)n);
   HIP_CHECK(hipMemset(t.d, 0, (size_t)std::max(n, 1) * sizeof(float)));
   HIP_CHECK(hipMemset(b1.d, 0, (size_t)std::max(n, 1) * sizeof(float)));
   HIP_CHECK(hipMemset(b2.d, 0, (size_t)std::max(n, 1) * sizeof(float)));
-  launch_trace_rays(s.scene, s.bvh_depth, n, o.d, d.d, t0.d, t1.d, any_hit, prim.d, t.d, b1.d, b2.d, s.stream);
+  launch_trace_rays(s.scene, s.bvh_depth, n, o.d, d.d, t0.d, t1.d, any_hit, prim.d, t.d, b1.d, b2.d, inst.d, s.stream);
   HIP_CHECK(hipStreamSynchronize(s.stream));
+  if (out_instance) inst.download(out_instance);
   if (out_prim) prim.download(out_prim);
   if (out_t) t.download(out_t);
   if (out_b1) b1.download(out_b1);
@@ -1457,6 +1564,7 @@ int pt_trace_rays(int n, const float* origins, const float* dirs, const float* t
 int pt_dbg_shade(int n, pt_path_rec* recs, const int* prim, const float* b1, const float* b2, int frame, int max_depth,
                  int* out_shadow_traced) {
   State& s = dbg_state();
+  if (s.scene.inst_records) return -1;  // single shading steps are offered for flat scenes only
   static_assert(sizeof(pt_path_rec) == sizeof(DbgPathRec), "layout");
   DevBuf<DbgPathRec> r(reinterpret_cast<const DbgPathRec*>(recs), (size_t)n);
   DevBuf<int> p(prim, (size_t)n), sh((size_t)n);

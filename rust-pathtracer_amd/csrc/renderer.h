@@ -57,6 +57,8 @@ struct State {
 
   // path state / queues
   q4 *st_o = nullptr, *st_d = nullptr, *st_s = nullptr, *acc = nullptr, *hits = nullptr;
+  uint32_t* hit_inst = nullptr;    // per queue slot: the instance of the hit (instanced scenes)
+  q4* d_inst = nullptr;            // instanced scenes: 6 q4 per instance (SceneView::inst_records)
   q4 *sh_o = nullptr, *sh_d = nullptr, *sh_c = nullptr;
   u4* st_m = nullptr;
   int* started = nullptr;

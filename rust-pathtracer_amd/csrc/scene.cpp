@@ -180,6 +180,72 @@ HostScene make_synthetic(uint32_t seed, int n_objects, int subdiv) {
   return s;
 }
 
+HostScene make_synthetic_instanced(uint32_t seed, int n_objects, int subdiv) {
+  HostScene s;
+  add_room(s);
+  HostScene::MeshRange room{0u, (uint32_t)s.num_tris()};
+  std::vector<V3> sv;
+  std::vector<uint32_t> st;
+  make_icosphere(subdiv < 0 ? 0 : subdiv, sv, st);
+  const uint32_t base = (uint32_t)(s.vertices.size() / 3);
+  for (const V3& v : sv) { s.vertices.push_back(v.x); s.vertices.push_back(v.y); s.vertices.push_back(v.z); }
+  for (uint32_t i : st) s.indices.push_back(base + i);
+  for (size_t i = 0; i < st.size() / 3; ++i) s.materials.push_back(make_material(kWhite, 0.25f, 0.f, kBlack));
+  HostScene::MeshRange ball{room.num_tris, (uint32_t)(st.size() / 3)};
+  s.meshes = {room, ball};
+  HostScene::Instance whole{};
+  whole.mesh = 0;
+  whole.xform[0] = whole.xform[5] = whole.xform[10] = 1.0f;
+  s.instances.push_back(whole);
+  // the placement, size and colour draws of make_synthetic, in its order
+  int g = 1;
+  while (g * g * g < n_objects) ++g;
+  Rng32 rng{seed ? seed : 1u};
+  const float cell_xy = 1.8f / (float)g, cell_z = 1.5f / (float)g;
+  const V3 palette[3] = {kWhite, kRed, kGreen};
+  int placed = 0;
+  for (int iz = 0; iz < g && placed < n_objects; ++iz)
+    for (int iy = 0; iy < g && placed < n_objects; ++iy)
+      for (int ix = 0; ix < g && placed < n_objects; ++ix, ++placed) {
+        const float radius = (0.25f + 0.15f * rng.unit()) * std::fmin(cell_xy, cell_z);
+        const V3 c{-0.9f + ((float)ix + 0.35f + 0.3f * rng.unit()) * cell_xy,
+                   -0.9f + ((float)iy + 0.35f + 0.3f * rng.unit()) * cell_xy,
+                   0.05f + ((float)iz + 0.35f + 0.3f * rng.unit()) * cell_z};
+        HostScene::Instance in{};
+        in.mesh = 1;
+        in.xform[0] = in.xform[5] = in.xform[10] = radius;
+        in.xform[3] = c.x; in.xform[7] = c.y; in.xform[11] = c.z;
+        in.has_material = 1;
+        in.material = make_material(palette[rng.next() % 3u], 0.25f, 0.f, kBlack);
+        s.instances.push_back(in);
+      }
+  s.compute_normals();
+  set_light(s);
+  return s;
+}
+
+HostScene HostScene::flattened() const {
+  if (!instanced()) return *this;
+  HostScene f;
+  for (const Instance& in : instances) {
+    const MeshRange& m = meshes[in.mesh];
+    for (uint32_t t = 0; t < m.num_tris; ++t) {
+      for (int k = 0; k < 3; ++k) {
+        const float* v = &vertices[3 * (size_t)indices[3 * (size_t)(m.first_tri + t) + k]];
+        f.indices.push_back((uint32_t)(f.vertices.size() / 3));
+        for (int r = 0; r < 3; ++r)
+          f.vertices.push_back(in.xform[4 * r] * v[0] + in.xform[4 * r + 1] * v[1] + in.xform[4 * r + 2] * v[2] + in.xform[4 * r + 3]);
+      }
+      f.materials.push_back(in.has_material ? in.material : materials[m.first_tri + t]);
+    }
+  }
+  f.compute_normals();
+  for (int k = 0; k < 3; ++k) { f.light_pos[k] = light_pos[k]; f.light_emit[k] = light_emit[k]; f.light_normal[k] = light_normal[k]; }
+  f.light_half[0] = light_half[0];
+  f.light_half[1] = light_half[1];
+  return f;
+}
+
 HostScene make_from_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                               const float* materials11) {
   HostScene s;

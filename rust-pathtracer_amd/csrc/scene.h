@@ -27,6 +27,22 @@ struct HostScene {
   float light_pos[3], light_emit[3], light_normal[3], light_half[2];
   int num_tris() const { return (int)(indices.size() / 3); }
   void compute_normals();
+
+  // A scene made of instances (no counterpart in the reference, whose pipeline allows single-level instancing,
+  // optix_wrapper.cpp:565-566, and never uses it): the arrays above then hold the meshes one after another in
+  // their own object space, and the picture is the set of instances.
+  struct MeshRange { uint32_t first_tri, num_tris; };
+  struct Instance {
+    uint32_t mesh;
+    float xform[12];      // object -> world, three rows of (x y z | translation)
+    int has_material;     // the instance replaces the mesh's per-triangle materials by one of its own
+    Material material;
+  };
+  std::vector<MeshRange> meshes;
+  std::vector<Instance> instances;
+  bool instanced() const { return !instances.empty(); }
+  // every instance written out in world space as plain triangles (what the instanced scene must look like)
+  HostScene flattened() const;
 };
 
 // The reference's built-in scene (optix_wrapper.cpp:379-489, light 842-845).
@@ -34,9 +50,18 @@ HostScene make_cornell();
 // Cornell room plus a seeded grid of subdivided icospheres (about n_objects * 20 * 4^subdiv
 // triangles) with materials drawn from the three wall colours.
 HostScene make_synthetic(uint32_t seed, int n_objects, int subdiv);
+// The same picture as instances: the room is one mesh placed once, the spheres are one unit icosphere placed
+// n_objects times with a scale, a translation and a material each.
+HostScene make_synthetic_instanced(uint32_t seed, int n_objects, int subdiv);
 // Caller geometry inside the reference's light set-up; materials11 may be null (white diffuse).
 HostScene make_from_triangles(const float* vertices, int n_vertices, const uint32_t* indices, int n_triangles,
                               const float* materials11);
+
+// Instanced scenes (scene_instances.cpp): the inverse of an affine object -> world matrix (false if singular), and
+// the two-level tree in the arrays of a flat one (layout: pt_bvh.h, TraceStateT<true>).
+struct BvhBuildResult;
+bool invert_affine(const float m[12], double inv[12]);
+BvhBuildResult build_instanced(const HostScene& hs);
 
 // Wavefront OBJ (+ MTL) in and out (scene_obj.cpp).  A loaded scene keeps the reference's rectangle light
 // for next-event estimation until the caller sets another one.  On failure `err` says why.

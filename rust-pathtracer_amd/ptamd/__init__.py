@@ -119,6 +119,14 @@ SIGNATURES = {
     "pt_set_bvh_pairing": (None, [C.c_int]),
     "pt_scene_load_obj": (C.c_int, [C.c_char_p]),
     "pt_scene_counts": (None, [_ip, _ip]),
+    "pt_scene_instanced_begin": (C.c_int, []),
+    "pt_scene_add_mesh": (C.c_int, [_fp, C.c_int, _u32p, C.c_int, _fp]),
+    "pt_scene_add_instance": (C.c_int, [C.c_int, _fp, _fp]),
+    "pt_scene_instanced_commit": (C.c_int, []),
+    "pt_scene_flatten": (C.c_int, []),
+    "pt_scene_instance_count": (C.c_int, []),
+    "pt_scene_synthetic_instanced": (None, [C.c_uint32, C.c_int, C.c_int]),
+    "pt_trace_rays_instances": (C.c_int, [C.c_int, _fp, _fp, _fp, _fp, C.c_int, _ip, _fp, _fp, _fp, _ip]),
     "pt_scene_save_obj": (C.c_int, [C.c_char_p]),
     "pt_scene_set_light": (None, [_fp, _fp, _fp, _fp]),
     "pt_scene_info": (None, [_ip, _ip, _ip, C.POINTER(C.c_size_t)]),
@@ -309,6 +317,41 @@ def trace_rays(origins, dirs, tmin=None, tmax=None, any_hit=False):
     b2 = np.zeros(n, np.float32)
     lib().pt_trace_rays(n, _f(o), _f(d), _f(t0), _f(t1), 1 if any_hit else 0, _i(prim), _f(t), _f(b1), _f(b2))
     return prim, t, b1, b2
+
+
+def trace_rays_instances(origins, dirs, tmin=None, tmax=None, any_hit=False):
+    """trace_rays that also returns the instance of every closest hit (-1: flat scene or miss)."""
+    o = np.ascontiguousarray(origins, np.float32)
+    d = np.ascontiguousarray(dirs, np.float32)
+    n = o.shape[0]
+    t0 = np.zeros(n, np.float32) if tmin is None else np.ascontiguousarray(tmin, np.float32)
+    t1 = np.full(n, 1e16, np.float32) if tmax is None else np.ascontiguousarray(tmax, np.float32)
+    prim, inst = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    t, b1, b2 = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib().pt_trace_rays_instances(n, _f(o), _f(d), _f(t0), _f(t1), 1 if any_hit else 0, _i(prim), _f(t), _f(b1), _f(b2), _i(inst))
+    return prim, t, b1, b2, inst
+
+
+def scene_instanced(meshes, instances):
+    """meshes: list of (vertices [nv,3], indices [nt,3], materials [nt,11] or None); instances: list of
+    (mesh id, xform [3,4] object -> world, material [11] or None).  Returns the number of instances."""
+    L = lib()
+    L.pt_scene_instanced_begin()
+    for V, I, M in meshes:
+        V = np.ascontiguousarray(V, np.float32)
+        I = np.ascontiguousarray(I, np.uint32)
+        M = None if M is None else np.ascontiguousarray(M, np.float32)
+        if L.pt_scene_add_mesh(_f(V), len(V), I.ctypes.data_as(_u32p), len(I), None if M is None else _f(M)) < 0:
+            raise ValueError("pt_scene_add_mesh refused the mesh")
+    for mesh, xform, mat in instances:
+        x = np.ascontiguousarray(xform, np.float32).reshape(12)
+        m = None if mat is None else np.ascontiguousarray(mat, np.float32)
+        if L.pt_scene_add_instance(mesh, _f(x), None if m is None else _f(m)) < 0:
+            raise ValueError("pt_scene_add_instance refused the instance")
+    n = L.pt_scene_instanced_commit()
+    if n < 0:
+        raise ValueError("pt_scene_instanced_commit: no instances")
+    return n
 
 
 def train_samples():

@@ -34,7 +34,8 @@ int g_origin_skip = 1;  // pass the primitive a ray leaves to trace_ray (must no
 
 void finish_scene() {
   const int nt = g_hs.num_tris();
-  g_bvh = build_bvh8(g_hs.vertices.data(), g_hs.indices.data(), nt);
+  if (g_hs.instanced()) g_bvh = build_instanced(g_hs);
+  else g_bvh = build_bvh8(g_hs.vertices.data(), g_hs.indices.data(), nt);
   g_recs.assign((size_t)(nt > 0 ? nt : 1), ShadeRec{});
   for (int i = 0; i < nt; ++i) {
     ShadeRec& r = g_recs[(size_t)i];
@@ -59,6 +60,7 @@ void finish_scene() {
   g_sv.wide = nullptr;
   g_sv.tris = g_bvh.tris.data();
   g_sv.shade = g_recs.data();
+  g_sv.inst_records = g_bvh.inst_records.empty() ? nullptr : g_bvh.inst_records.data();
   g_sv.num_tris = (uint32_t)nt;
   g_sv.num_items = (uint32_t)g_bvh.num_items;
   g_sv.vmag = g_bvh.vmag;
@@ -89,6 +91,26 @@ extern "C" {
 
 void hc_scene_cornell() { g_hs = make_cornell(); finish_scene(); }
 void hc_scene_synthetic(uint32_t seed, int n, int subdiv) { g_hs = make_synthetic(seed, n, subdiv); finish_scene(); }
+// the same picture as instances of a room and a unit icosphere, the current scene written out flat, and a scene
+// of caller meshes and placements (xforms: 12 floats per instance, object -> world rows)
+void hc_scene_synthetic_instanced(uint32_t seed, int n, int subdiv) { g_hs = make_synthetic_instanced(seed, n, subdiv); finish_scene(); }
+void hc_scene_flatten() { ensure(); g_hs = g_hs.flattened(); finish_scene(); }
+int hc_scene_instances(const float* v, int nv, const uint32_t* idx, int nt, int n_inst, const float* xforms) {
+  HostScene s = make_from_triangles(v, nv, idx, nt, nullptr);
+  s.meshes.push_back(HostScene::MeshRange{0u, (uint32_t)nt});
+  for (int i = 0; i < n_inst; ++i) {
+    HostScene::Instance in{};
+    in.mesh = 0;
+    memcpy(in.xform, xforms + 12 * i, sizeof(in.xform));
+    double inv[12];
+    if (!invert_affine(in.xform, inv)) return -1;
+    s.instances.push_back(in);
+  }
+  g_hs = s;
+  finish_scene();
+  return n_inst;
+}
+int hc_num_instances() { ensure(); return (int)g_hs.instances.size(); }
 void hc_scene_triangles(const float* v, int nv, const uint32_t* idx, int nt, const float* m11) {
   g_hs = make_from_triangles(v, nv, idx, nt, m11); finish_scene();
 }
@@ -144,6 +166,29 @@ void hc_trace_rays(int n, const float* o, const float* d, const float* tmin, con
     else {
       if (h.prim >= 0) to_input_order(g_sv.shade[h.prim].corner_order, h.b1, h.b2);
       prim[i] = h.prim; t[i] = h.t; b1[i] = h.b1; b2[i] = h.b2;
+    }
+  }
+}
+
+// Instanced scenes: the step-wise traversal the staged kernels run (TraceStateT<true>); prim is the index into the
+// meshes' concatenated triangles, inst the instance of the hit.
+void hc_trace_rays_instanced(int n, const float* o, const float* d, const float* tmin, const float* tmax, int any_hit,
+                             int* prim, float* t, float* b1, float* b2, int* inst) {
+  ensure();
+  for (int i = 0; i < n; ++i) {
+    LocalStack st;
+    const f3 ro = mk3(o[3*i], o[3*i+1], o[3*i+2]), rd = mk3(d[3*i], d[3*i+1], d[3*i+2]);
+    TraceStateT<true> ts;
+    ts.begin(g_sv, ro, rd, tmax[i], 0u);
+    while (!ts.done()) {
+      if (ts.wants_node()) ts.node_step(g_sv, ro, rd, tmin[i], st, 64);
+      if (ts.wants_tri() && ts.tri_step(g_sv, ro, rd, tmin[i], any_hit != 0, st, 64)) ts.finish();
+    }
+    Hit h = ts.hit;
+    if (any_hit) { prim[i] = h.prim >= 0 ? 1 : 0; }
+    else {
+      if (h.prim >= 0) to_input_order(g_sv.shade[h.prim].corner_order, h.b1, h.b2);
+      prim[i] = h.prim; t[i] = h.t; b1[i] = h.b1; b2[i] = h.b2; inst[i] = h.prim >= 0 ? (int)ts.hit_inst : -1;
     }
   }
 }

@@ -1352,6 +1352,59 @@ def test_large_scene_at_its_own_size(gpu):
         L.pt_set_defer_shadow(1)
 
 
+def test_instanced_scene_traces_and_renders_like_its_flat_copy(gpu, oracle):
+    """A scene made of instances (two-level tree, rays taken to object space, normals brought back through the inverse
+    transpose, a material per instance) against the same scene written out as world-space triangles: the closest
+    hits are the oracle's brute-force hits, and the renders agree as two renders of one scene do."""
+    L = gpu.lib()
+    rng = np.random.default_rng(5)
+    try:
+        L.pt_scene_synthetic_instanced(42, 125, 3)
+        assert L.pt_scene_instance_count() == 126
+        o = rng.uniform(-0.95, 0.95, (20000, 3)).astype(np.float32)
+        o[:, 2] = rng.uniform(0.02, 1.98, len(o))
+        d = rng.normal(size=(len(o), 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        prim, t, b1, b2, inst = gpu.trace_rays_instances(o, d)
+        tmax = rng.uniform(0.05, 2.0, len(o)).astype(np.float32)
+        occ = gpu.trace_rays_instances(o, d, tmax=tmax, any_hit=True)[0]
+        L.pt_set_frame(0)
+        a = [gpu.render_rgb(96, 54, 256) for _ in range(2)]
+        info = gpu.scene_info()
+        assert info["triangles"] == 12 + 1280  # the meshes only
+        assert L.pt_render_accumulate_device_noalloc(16, 16, 0, 4, 8, 1, None) != 0  # refused, not rendered wrongly
+        # ... and its flat copy
+        assert L.pt_scene_flatten() == 12 + 125 * 1280 and L.pt_scene_instance_count() == 0
+        fprim, ft, fb1, fb2 = gpu.trace_rays(o, d)
+        focc = gpu.trace_rays(o, d, tmax=tmax, any_hit=True)[0]
+        flat = np.where(prim < 0, -1, np.where(inst == 0, prim, 12 + (inst - 1) * 1280 + (prim - 12)))
+        assert (flat != fprim).mean() < 1e-3 and ((fprim >= 0) == (prim >= 0)).all()
+        same = flat == fprim
+        assert np.abs(t - ft)[same & (fprim >= 0)].max() < 3e-5 and np.abs(t - ft)[fprim >= 0].max() < 1e-4
+        assert (occ != focc).mean() < 5e-4
+        V, I, _, _ = gpu.scene_arrays()
+        oracle.lib().orc_scene_set(P(V), len(V), P(I, C.c_uint32), len(I), None)
+        fp = C.POINTER(C.c_float)
+        sel = np.arange(0, len(o), 10)
+        want = np.array([oracle.lib().orc_trace_closest(o[i].ctypes.data_as(fp), d[i].ctypes.data_as(fp), 0.0, 1e16).prim for i in sel])
+        assert (flat[sel] != want).mean() < 2e-3
+        L.pt_set_frame(0)
+        b = [gpu.render_rgb(96, 54, 256) for _ in range(2)]
+        L.pt_set_pipeline(0)
+        L.pt_set_frame(0)
+        c = gpu.render_rgb(96, 54, 256)
+        assert np.array_equal(c, b[0]) or rel_rmse(c, b[0]) < 1e-4  # flat scene: staged = default pipeline
+        for ch in range(3):
+            ma, mb = [x[..., ch].mean() for x in a], [x[..., ch].mean() for x in b]
+            sigma = max(abs(ma[0] - ma[1]), abs(mb[0] - mb[1])) / np.sqrt(2) + 2e-3 * mb[0]
+            assert abs(np.mean(ma) - np.mean(mb)) < 3 * sigma, (ch, ma, mb)
+        assert rel_rmse(a[0], b[0]) < 1.6 * rel_rmse(b[1], b[0]) + 0.01  # as far apart as two renders of the flat scene
+    finally:
+        oracle.lib().orc_scene_set(None, 0, None, 0, None)
+        L.pt_set_pipeline(-1)
+        L.pt_scene_cornell()
+
+
 def test_full_size_1080p_properties(gpu):
     """BASELINE's 1080p configuration at reduced spp: properties that do not need a CPU render."""
     L = gpu.lib()

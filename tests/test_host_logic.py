@@ -909,3 +909,110 @@ def test_binned_guiding_across_two_ranks(pt, tmp_path):
     finally:
         one.close()
 
+
+# ------------------------------------------------------------------ scenes made of instances (two-level tree)
+def _hc_trace_instanced(hc, o, d, tmax=None, any_hit=0):
+    n = len(o)
+    tmin = np.zeros(n, np.float32)
+    tmax = np.full(n, 1e16, np.float32) if tmax is None else tmax
+    prim, inst = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    t, b1, b2 = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    hc.hc_trace_rays_instanced(n, P(o), P(d), P(tmin), P(tmax), any_hit, P(prim, C.c_int), P(t), P(b1), P(b2), P(inst, C.c_int))
+    return prim, t, b1, b2, inst
+
+
+def test_instanced_scene_flattens_to_the_flat_one(hostcheck):
+    """The synthetic scene as instances (room placed once, one unit icosphere placed per object with a scale, a
+    translation and a colour) written out in world space is the flat synthetic scene: same triangles, same materials."""
+    hostcheck.hc_scene_synthetic(7, 27, 2)
+    try:
+        want = _scene_arrays(hostcheck)
+        hostcheck.hc_scene_synthetic_instanced(7, 27, 2)
+        assert hostcheck.hc_num_instances() == 28
+        nt = C.c_int(); nn = C.c_int(); dp = C.c_int()
+        hostcheck.hc_scene_info(C.byref(nt), C.byref(nn), C.byref(dp))
+        assert nt.value == 12 + 320  # the meshes: one room, one sphere
+        hostcheck.hc_scene_flatten()
+        got = _scene_arrays(hostcheck)
+        V0, I0, N0, M0 = want[:4]
+        V1, I1, N1, M1 = got[:4]
+        assert len(I0) == len(I1) and np.array_equal(V0[I0], V1[I1]) and np.array_equal(M0, M1)
+    finally:
+        hostcheck.hc_scene_cornell()
+
+
+def test_instanced_traversal_matches_brute_force(hostcheck, oracle):
+    """Rays through the two-level tree (top level over instance boxes, the ray taken to object space inside an
+    instance) find what the oracle's brute-force loop finds in the same scene written out as world triangles:
+    the same triangle of the same instance at the same distance, and the same occlusion."""
+    hostcheck.hc_scene_synthetic_instanced(7, 64, 2)
+    try:
+        o, d = _random_rays(3000, 21)
+        prim, t, b1, b2, inst = _hc_trace_instanced(hostcheck, o, d)
+        tmax = np.random.default_rng(22).uniform(0.05, 2.0, len(o)).astype(np.float32)
+        occ = _hc_trace_instanced(hostcheck, o, d, tmax, any_hit=1)[0]
+        hostcheck.hc_scene_flatten()
+        V, I, N, M, nodes, depth = _scene_arrays(hostcheck)
+        assert len(I) == 12 + 64 * 320
+        oracle.lib().orc_scene_set(P(V), len(V), P(I, C.c_uint32), len(I), None)
+        op, ot = _orc_trace(oracle, o, d)
+        # flat triangle index of (instance, triangle of the meshes): instance 0 is the room, the others one sphere each
+        flat = np.where(inst == 0, prim, 12 + (inst - 1) * 320 + (prim - 12))
+        flat = np.where(prim < 0, -1, flat)
+        assert (flat != op).sum() == 0
+        assert np.abs(t - ot)[op >= 0].max() < 2e-5
+        assert ((b1 >= -1e-5) & (b2 >= -1e-5) & (b1 + b2 <= 1.0 + 1e-5))[op >= 0].all()
+        L = oracle.lib()
+        fp = C.POINTER(C.c_float)
+        want = np.array([L.orc_trace_any(o[i].ctypes.data_as(fp), d[i].ctypes.data_as(fp), 0.0, float(tmax[i]))
+                         for i in range(len(o))])
+        assert (occ != want).sum() <= 2  # a blocker within rounding of tmax may fall either side in object space
+        # the flat tree over the same triangles agrees too
+        fprim, ft, _, _ = _hc_trace(hostcheck, o, d)
+        assert np.array_equal(fprim, op) and np.abs(ft - t)[op >= 0].max() < 2e-5
+    finally:
+        oracle.lib().orc_scene_set(None, 0, None, 0, None)
+        hostcheck.hc_scene_cornell()
+
+
+def test_instances_under_rotation_and_uneven_scale(hostcheck, oracle):
+    """General affine placements: rotated, unevenly scaled and mirrored copies of one mesh, overlapping each other."""
+    rng = np.random.default_rng(31)
+    # one mesh: a unit octahedron
+    V = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    I = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.uint32)
+    xf = []
+    for k in range(40):
+        a = rng.normal(size=(3, 3))
+        q, _ = np.linalg.qr(a)
+        m = q @ np.diag(rng.uniform(0.05, 0.4, 3) * rng.choice([-1, 1], 3))
+        tr = rng.uniform(-0.8, 0.8, 3) + [0, 0, 1]
+        xf.append(np.concatenate([m, tr[:, None]], 1).reshape(-1))
+    xf = np.array(xf, np.float32)
+    assert hostcheck.hc_scene_instances(P(V), len(V), P(I, C.c_uint32), len(I), len(xf), P(xf)) == 40
+    try:
+        o, d = _random_rays(4000, 32)
+        prim, t, b1, b2, inst = _hc_trace_instanced(hostcheck, o, d)
+        hostcheck.hc_scene_flatten()
+        FV, FI, _, _, _, _ = _scene_arrays(hostcheck)
+        oracle.lib().orc_scene_set(P(FV), len(FV), P(FI, C.c_uint32), len(FI), None)
+        op, ot = _orc_trace(oracle, o, d)
+        flat = np.where(prim < 0, -1, inst * 8 + prim)
+        bad = flat != op
+        # two overlapping copies can be hit at distances that differ by rounding only: then either is the closest
+        assert (np.abs(t - ot)[bad & (op >= 0) & (prim >= 0)] < 1e-5).all() and ((op >= 0) == (prim >= 0)).all()
+        assert bad.mean() < 0.002 and (op >= 0).mean() > 0.3
+        assert np.abs(t - ot)[op >= 0].max() < 3e-5
+        # the point the hit describes (barycentrics on the world-space triangle) lies on the ray
+        hit = (op >= 0) & ~bad
+        tri = FV[FI[flat[hit]]]
+        pt_ = tri[:, 0] * (1 - b1[hit] - b2[hit])[:, None] + tri[:, 1] * b1[hit][:, None] + tri[:, 2] * b2[hit][:, None]
+        assert np.abs(pt_ - (o[hit] + d[hit] * t[hit][:, None])).max() < 1e-4
+        # a transform that cannot be inverted is refused
+        bad_xf = xf[:1].copy()
+        bad_xf[0, 0:3] = 0
+        assert hostcheck.hc_scene_instances(P(V), len(V), P(I, C.c_uint32), len(I), 1, P(bad_xf)) == -1
+    finally:
+        oracle.lib().orc_scene_set(None, 0, None, 0, None)
+        hostcheck.hc_scene_cornell()
+

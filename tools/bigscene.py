@@ -5,7 +5,9 @@ import numpy as np, ptamd
 L = ptamd.lib()
 n, sub = int(sys.argv[1]), int(sys.argv[2])
 w, h, spp = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-L.pt_scene_synthetic(42, n, sub)
+import os
+if os.environ.get('INSTANCED'): L.pt_scene_synthetic_instanced(42, n, sub)  # room + one unit icosphere placed n times
+else: L.pt_scene_synthetic(42, n, sub)
 t = time.time(); img = ptamd.render_rgb(64, 36, 1); print("scene+bvh+first render", round(time.time() - t, 2), "s", ptamd.scene_info(), flush=True)
 for pipe in (-1, 1, 0):
     L.pt_set_pipeline(pipe)

@@ -5,7 +5,9 @@ sys.path.insert(0, "rust-pathtracer_amd"); sys.path.insert(0, "tests")
 import ptamd
 L = ptamd.lib()
 n, sub, w, h = (int(a) for a in sys.argv[1:5])
-L.pt_scene_synthetic(42, n, sub)
+import os
+if os.environ.get('INSTANCED'): L.pt_scene_synthetic_instanced(42, n, sub)  # room + one unit icosphere placed n times
+else: L.pt_scene_synthetic(42, n, sub)
 ptamd.render_rgb(64, 36, 1)
 for spp in (int(a) for a in sys.argv[5:]):
     for pipe in (0, -1):
