@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
     else if (arg_value(a, "--scene", v)) {
       int n = 0, sub = 3;
       if (v == "cornell") pt_scene_cornell();
+      else if (sscanf(v.c_str(), "instanced:%d:%d", &n, &sub) >= 1) pt_scene_synthetic_instanced(42u, n, sub);  // the same picture as instances
       else if (sscanf(v.c_str(), "synthetic:%d:%d", &n, &sub) >= 1) pt_scene_synthetic(42u, n, sub);
       else if (pt_scene_load_obj(v.c_str()) < 0) return 2;  // anything else is the path of an OBJ file
     }

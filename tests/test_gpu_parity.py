@@ -393,6 +393,43 @@ def test_shade_step_means_match_quadrature(gpu, oracle, case):
     assert ok.mean() > 0.99 and (np.abs(mean - e_lo) < 4.5 * sem + 2e-3 * e_lo).all(), (mean, e_lo, sem)
 
 
+def test_glass_and_emission_follow_their_formulas_on_the_gpu(gpu, oracle):
+    """The GPU shading step at the glass box and at the light against closed forms (tests/test_oracle_golden.py:
+    Schlick's reflection share, Snell's law, total internal reflection, the restart offset; emission weighted by
+    the balance heuristic).  The oracle is only asked for the scene's tables."""
+    from test_oracle_golden import glass_cases, check_glass_step, light_hit_cases, expected_light_hit
+    t_in = np.array([0.9, 0.7, 0.5])
+    shade = _gpu_shade(gpu)
+    N = 6000
+    seeds = np.random.default_rng(3).integers(0, 2 ** 63, N, dtype=np.uint64)
+    for prim, point, n, ior, base, d, inside in glass_cases(oracle):
+        recs = (HcRec * N)()
+        eye = (point - 0.5 * d).astype(np.float32)
+        for i in range(N):
+            r = recs[i]
+            r.throughput[:] = t_in.tolist()
+            r.origin[:] = eye.tolist()
+            r.direction[:] = d.astype(np.float32).tolist()
+            r.seed, r.rng_dim = int(seeds[i]), 2
+        out, _ = shade(recs, np.full(N, prim, np.int32), np.full(N, 0.3, np.float32), np.full(N, 0.3, np.float32))
+        f = np.frombuffer(out, dtype=np.uint8).reshape(N, C.sizeof(HcRec))[:, :48].copy().view(np.float32).reshape(N, 12)
+        check_glass_step([(f[i, 9:12], f[i, 6:9], f[i, 3:6]) for i in range(N)], n, ior, base, d, inside, point, t_in)
+    cases = [(c, prev) for c in light_hit_cases(oracle) for prev in (None, 0.05, 0.8, 30.0)]
+    recs = (HcRec * len(cases))()
+    for r, ((prim, b1, b2, point, emission, org, d), prev) in zip(recs, cases):
+        r.throughput[:] = [1.0, 1.0, 1.0]
+        r.origin[:] = org.tolist()
+        r.direction[:] = d.tolist()
+        r.seed, r.depth, r.rng_dim = 12345, 1, 2
+        r.prev_pdf_valid, r.prev_pdf_bsdf = (0, 0.0) if prev is None else (1, prev)
+    out, _ = shade(recs, np.array([c[0][0] for c in cases], np.int32), np.array([c[0][1] for c in cases], np.float32),
+                   np.array([c[0][2] for c in cases], np.float32))
+    f = np.frombuffer(out, dtype=np.uint8).reshape(len(cases), C.sizeof(HcRec))[:, :48].copy().view(np.float32).reshape(-1, 12)
+    for row, ((prim, b1, b2, point, emission, org, d), prev) in zip(f.astype(np.float64), cases):
+        want = expected_light_hit(point, emission, org, d, prev)
+        assert np.allclose(row[0:3] / row[3:6], want, rtol=1e-4), (row[0:3] / row[3:6], want)  # contribution / throughput after
+
+
 def test_vmf_samples_on_the_gpu_follow_their_density(gpu):
     """vmf_sample on the device (through pt_dbg_guiding, one region, one lobe) against the analytic von
     Mises-Fisher cdf and a uniform azimuth, chi-square, for a broad, a medium and a sharp lobe; the mixture pdf
