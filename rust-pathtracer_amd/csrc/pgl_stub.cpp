@@ -126,7 +126,7 @@ void pgl_field_update(pgl_field_t field_handle, pgl_samples_t samples_handle) {
     bool inside = true;
     for (int k = 0; k < 3; ++k) {
       const float ext = f->bmax[k] - f->bmin[k];
-      if (it.pos[k] < f->bmin[k] || it.pos[k] > f->bmax[k] || !(ext > 0.f)) { inside = false; break; }
+      if (!(it.pos[k] >= f->bmin[k] && it.pos[k] <= f->bmax[k]) || !(ext > 0.f)) { inside = false; break; }  // a NaN is outside
       c[k] = (int)((it.pos[k] - f->bmin[k]) / ext * (float)f->res[k]);
       if (c[k] >= f->res[k]) c[k] = f->res[k] - 1;
     }

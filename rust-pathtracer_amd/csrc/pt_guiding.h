@@ -94,7 +94,7 @@ PT_HD bool bin_train_record(const TrainRec& rec, const BinField& f, const float*
   int c[3];
   for (int k = 0; k < 3; ++k) {
     const float ext = f.bmax[k] - f.bmin[k];
-    if (rec.position[k] < f.bmin[k] || rec.position[k] > f.bmax[k] || !(ext > 0.f)) return false;
+    if (!(rec.position[k] >= f.bmin[k] && rec.position[k] <= f.bmax[k]) || !(ext > 0.f)) return false;  // a NaN is outside
     c[k] = (int)((rec.position[k] - f.bmin[k]) / ext * (float)f.res[k]);
     if (c[k] >= f.res[k]) c[k] = f.res[k] - 1;
   }

@@ -1472,7 +1472,8 @@ int pt_scene_load_obj(const char* path) {
 }
 int pt_scene_save_obj(const char* path) {
   std::string err;
-  if (!path || !save_obj(path, scene(), err)) {
+  // a scene made of instances is written as the world-space triangles it stands for
+  if (!path || !save_obj(path, scene().instanced() ? scene().flattened() : scene(), err)) {
     fprintf(stderr, "[pt_hip] pt_scene_save_obj: %s\n", path ? err.c_str() : "null path");
     return -1;
   }

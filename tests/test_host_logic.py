@@ -854,6 +854,24 @@ def test_binned_update_is_the_sample_update(pt):
         b.close()
 
 
+def test_trainer_drops_records_that_are_not_numbers(pt):
+    """A position or weight that is not a finite number trains nothing, on either path (the comparison against the
+    field's bounds must not let a NaN through to the cell index)."""
+    import binning
+    f = pt.GuidingField((-1, -1, 0), (1, 1, 2))
+    try:
+        rec = np.zeros((4, 10), np.float32)
+        rec[:, 5] = 1.0
+        rec[:, 6:9] = 1.0
+        rec[0, 0], rec[1, 1], rec[2, 6] = np.nan, np.inf, np.nan
+        assert binning.bin_records(rec, *f.layout())[7::8].sum() == 1
+        f.update(rec)
+        regions, lobes = f.snapshot()
+        assert len(regions) == 64 and len(lobes) == 1 and lobes[0, 2] > 0.99
+    finally:
+        f.close()
+
+
 _BINNED_WORKER = r'''
 import sys
 import numpy as np, torch, torch.distributed as dist
