@@ -75,6 +75,55 @@ PT_HD float guiding_mixture_pdf(const GuideLobeDev* L, uint32_t lobe_num, float 
   return sum > 0.f ? pdf * rcp(sum) : 0.f;
 }
 
+// The two passes over a region's lobes with their loads issued together.  A lobe record is four 16-byte words
+// (mu kappa | cdf c k2 term | rgb 1/kappa | axis weight); regions of up to kGuideBatch lobes -- what trainers
+// produce -- read the second word of all their lobes at once for the choice and the first word of all of them at
+// once for the mixture pdf, instead of one dependent load per lobe and pass (each a round trip to L2 from a kernel
+// that otherwise never leaves the CU).  Loads past the region's last lobe re-read that lobe and are ignored.
+constexpr uint32_t kGuideBatch = 4;
+struct GuideBatch {
+  float cdf[kGuideBatch], c[kGuideBatch], k2[kGuideBatch];  // per lobe: running weight sum, weight x normalisation, kappa x log2(e)
+};
+// the second word of every lobe of the region (lobe_num in 1..kGuideBatch), all loads in flight together
+PT_HD void guiding_load_batch(const GuideLobeDev* L, uint32_t lobe_num, GuideBatch& gb) {
+  const q4* w = reinterpret_cast<const q4*>(L);
+  q4 b[kGuideBatch];
+#pragma unroll
+  for (uint32_t i = 0; i < kGuideBatch; ++i) b[i] = w[4u * (i < lobe_num ? i : lobe_num - 1u) + 1u];
+#pragma unroll
+  for (uint32_t i = 0; i < kGuideBatch; ++i) { gb.cdf[i] = b[i].x; gb.c[i] = b[i].y; gb.k2[i] = b[i].z; }
+}
+// guiding_choose_lobe on a loaded batch
+PT_HD int guiding_choose_lobe_batch(const GuideBatch& gb, uint32_t lobe_num, float sum, float u) {
+  if (sum <= 0.f) return -1;
+  const float r = u * sum;
+  int idx = (int)lobe_num - 1;
+#pragma unroll
+  for (int i = (int)kGuideBatch - 2; i >= 0; --i)  // descending, so that the first lobe whose running sum reaches r wins
+    if ((uint32_t)i + 1u < lobe_num && r <= gb.cdf[i]) idx = i;
+  return idx;
+}
+// the first word (mu, kappa) of every lobe of the region, all loads in flight together ...
+struct GuideAxes {
+  q4 a[kGuideBatch];
+};
+PT_HD void guiding_load_axes(const GuideLobeDev* L, uint32_t lobe_num, GuideAxes& ga) {
+  const q4* w = reinterpret_cast<const q4*>(L);
+#pragma unroll
+  for (uint32_t i = 0; i < kGuideBatch; ++i) ga.a[i] = w[4u * (i < lobe_num ? i : lobe_num - 1u)];
+}
+// ... and guiding_mixture_pdf on what was loaded
+PT_HD float guiding_mixture_pdf_batch(const GuideAxes& ga, const GuideBatch& gb, uint32_t lobe_num, float sum, f3 wi) {
+  float pdf = 0.f;
+#pragma unroll
+  for (uint32_t i = 0; i < kGuideBatch; ++i) {
+    const q4 a = ga.a[i];
+    const float e = a.w <= 1e-4f ? 1.0f : fexp2(gb.k2[i] * (dot(mk3(a.x, a.y, a.z), wi) - 1.f));
+    if (i < lobe_num) pdf += gb.c[i] * e;
+  }
+  return sum > 0.f ? pdf * rcp(sum) : 0.f;
+}
+
 // ---- training statistics binned on the device
 // The trainer's field as the binning kernel needs it: bounds, resolution, and (separately) the axis of every lobe.
 struct BinField {

@@ -10,6 +10,10 @@
 #include "pt_rng.h"
 #include "pt_types.h"
 
+#ifndef PT_GUIDE_EARLY_BATCH
+#define PT_GUIDE_EARLY_BATCH 1
+#endif
+
 namespace pt {
 
 // Register image of one path.  In HBM it is four 16-byte SoA streams:
@@ -241,7 +245,12 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
     // The guiding field's cell record is asked for here, well before the diffuse branch needs it, so that its
     // trip to memory runs beside the next-event arithmetic (optix_device.cu:596-612 does the lookup in place).
     GuideRegionDev guide_cell{0u, 0u, 0.0f, 0.0f};
-    if (GUIDED && sp.guiding) guide_cell = guiding_cell(gv, P);
+    GuideBatch gb;
+    if (GUIDED && sp.guiding) {
+      guide_cell = guiding_cell(gv, P);
+      if (PT_GUIDE_EARLY_BATCH && guide_cell.lobe_num > 0u && guide_cell.lobe_num <= kGuideBatch)
+        guiding_load_batch(gv.lobes + guide_cell.lobe_ofs, guide_cell.lobe_num, gb);
+    }
 
     // optix_device.cu:495-548: next-event estimation towards the rectangle light
     f3 Lo = mk3(0.0f);
@@ -340,14 +349,21 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
       }
       bool used_guiding = false;
       if (have_guiding) {
-        const int lobe_idx = guiding_choose_lobe(lobes, lobe_num, lobe_sum, next_rand(ps, rc));
+        const bool batch = lobe_num <= kGuideBatch;
+        if (!PT_GUIDE_EARLY_BATCH && batch) guiding_load_batch(lobes, lobe_num, gb);
+        const float u_lobe = next_rand(ps, rc);
+        const int lobe_idx = batch ? guiding_choose_lobe_batch(gb, lobe_num, lobe_sum, u_lobe)
+                                   : guiding_choose_lobe(lobes, lobe_num, lobe_sum, u_lobe);
         if (lobe_idx >= 0) {
           const float ux = next_rand(ps, rc);
           const float uy = next_rand(ps, rc);
           const GuideLobeDev lb = lobes[lobe_idx];
+          GuideAxes ga;
+          if (batch) guiding_load_axes(lobes, lobe_num, ga);  // in flight together with the chosen lobe's record
           const f3 gdir = vmf_sample(lb, ux, uy);
           const float cosG = fmaxf(dot(gdir, Ng), 0.0f);
-          const float p_g = guiding_mixture_pdf(lobes, lobe_num, lobe_sum, gdir);
+          const float p_g = batch ? guiding_mixture_pdf_batch(ga, gb, lobe_num, lobe_sum, gdir)
+                                  : guiding_mixture_pdf(lobes, lobe_num, lobe_sum, gdir);
           const float p_b = cosG * kInvPi;
           const float ch2 = next_rand(ps, rc) * (p_g + p_b);
           if (ch2 < p_g) {
