@@ -212,6 +212,28 @@ void hc_guide_set(const float* regions8, int nr, const float* lobes8, int nl, co
   g_guiding = enabled;
 }
 
+// The two forms of the passes over a region's lobes (pt_guiding.h): one load per lobe and pass, or the region's
+// lobes loaded in batches.  lobes8: n <= 4 lobes in the snapshot layout; returns the chosen lobe and the mixture pdf
+// of direction wi in both forms.
+void hc_guide_lobe_passes(const float* lobes8, int n, float u, const float* wi, int* idx_loop, int* idx_batch,
+                          float* pdf_loop, float* pdf_batch) {
+  std::vector<GuideLobe> in((size_t)n);
+  memcpy(in.data(), lobes8, (size_t)n * 32);
+  GuideRegion reg{{0, 0, 0}, {1, 1, 1}, 0u, (uint32_t)n};
+  GuideRegionDev rd;
+  std::vector<GuideLobeDev> dev((size_t)n);
+  make_guide_records(&reg, 1u, in.data(), (uint32_t)n, &rd, dev.data());
+  const f3 w = mk3(wi[0], wi[1], wi[2]);
+  *idx_loop = guiding_choose_lobe(dev.data(), (uint32_t)n, rd.sum, u);
+  *pdf_loop = guiding_mixture_pdf(dev.data(), (uint32_t)n, rd.sum, w);
+  GuideBatch gb;
+  GuideAxes ga;
+  guiding_load_batch(dev.data(), (uint32_t)n, gb);
+  guiding_load_axes(dev.data(), (uint32_t)n, ga);
+  *idx_batch = guiding_choose_lobe_batch(gb, (uint32_t)n, rd.sum, u);
+  *pdf_batch = guiding_mixture_pdf_batch(ga, gb, (uint32_t)n, rd.sum, w);
+}
+
 struct HcRec {
   float radiance[3], throughput[3], origin[3], direction[3];
   unsigned long long seed; int depth, done; float prev_pdf_bsdf; int prev_pdf_valid; int px, py, sample, rng_dim;

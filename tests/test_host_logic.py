@@ -821,6 +821,29 @@ def test_guiding_across_two_ranks(pt, tmp_path):
     assert len(l1) >= 1 and seen["l"] is l1 and l1[np.argmax(l1[:, 4]), 2] > 0.9
 
 
+def test_batched_lobe_passes_are_the_loops(hostcheck):
+    """Regions of up to four lobes are read in batches on the shading path; the lobe chosen and the mixture pdf
+    are those of the lobe-by-lobe loops, bit for bit -- also with zero weights, with one lobe, and with running
+    sums that repeat (the first lobe that reaches u x total wins in both)."""
+    rng = np.random.default_rng(17)
+    for trial in range(3000):
+        n = int(rng.integers(1, 5))
+        lobes = np.zeros((n, 8), np.float32)
+        mu = rng.normal(size=(n, 3))
+        lobes[:, 0:3] = mu / np.linalg.norm(mu, axis=1, keepdims=True)
+        lobes[:, 3] = rng.choice([0.0, 1e-5, 0.5, 7.0, 60.0], n)
+        lobes[:, 4] = rng.choice([0.0, 0.0, 1.0, 0.25], n) * rng.uniform(0.5, 1.0, n)
+        lobes[:, 5:8] = 1.0
+        wi = rng.normal(size=3)
+        wi = (wi / np.linalg.norm(wi)).astype(np.float32)
+        u = float(rng.choice([0.0, 0.25, 0.5, 0.999999, float(rng.uniform())]))
+        il, ib = C.c_int(), C.c_int()
+        pl, pb = C.c_float(), C.c_float()
+        hostcheck.hc_guide_lobe_passes(P(lobes), n, C.c_float(u), P(wi), C.byref(il), C.byref(ib), C.byref(pl), C.byref(pb))
+        assert il.value == ib.value, (trial, lobes, u)
+        assert np.float32(pl.value).tobytes() == np.float32(pb.value).tobytes(), (trial, pl.value, pb.value)
+
+
 # ------------------------------------------------------------------ training statistics binned per region and lobe
 def _random_records(rng, n):
     rec = np.zeros((n, 10), np.float32)
