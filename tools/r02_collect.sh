@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 measurements behind profiles/r02_*: one GPU call.  Run from the repository root.
+# The measurements behind profiles/r02_*: one GPU call.  Run from the repository root.
 # Every rocprofv3 step is its own run under its own time limit; counters never share a run with a trace.
 export TMPDIR=/tmp
 set -e

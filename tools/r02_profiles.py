@@ -36,7 +36,7 @@ def main():
     final = json.loads(rd("bench_final.json"))
     tf, avg = table(f"{SRC}/prof_f/pf_kernel_stats.csv")
     r = prof["roofline"]
-    open("profiles/r02_kernel_stats.md", "w").write(f"""# Round 2 -- kernel statistics (rocprofv3 --kernel-trace --stats; durations in microseconds)
+    open("profiles/r02_kernel_stats.md", "w").write(f"""# Kernel statistics, r02 (rocprofv3 --kernel-trace --stats; durations in microseconds)
 
 ## fused pipeline (default), 1080p 1024 spp, 1 step
 
