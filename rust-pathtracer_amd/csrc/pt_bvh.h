@@ -119,8 +119,10 @@ constexpr int kTriWords = 4;
 // of an edge goes to the watertight test on the original vertices (intersect_triangle), so shared
 // edges and vertices keep the watertight test's answer and no ray slips between two triangles.
 // Returns 0 miss, 1 hit (hit updated), 2 undecided.
+// dlen: an upper bound of |d| (1 for the unit directions of world-space rays; a ray taken into an instance's object
+// space keeps its parameter and so has a direction of another length).
 PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, f3 o, f3 d, float rmag, float tmin,
-                        Hit& hit) {
+                        Hit& hit, float dlen = 1.0f) {
   // every kernel must get the same bits out of this test: products and sums are fused only where written
 #if defined(__clang__)
 #pragma clang fp contract(off)
@@ -136,7 +138,7 @@ PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, 
   float b1 = __builtin_fmaf(t, shear_dot(r1, d), shear_dot(r1, A));
   float b2 = __builtin_fmaf(t, shear_dot(r2, d), shear_dot(r2, A));
   const float b0 = 1.0f - b1 - b2;
-  const float eps = q0.w * (rmag + fabsf(t));
+  const float eps = q0.w * (rmag + fabsf(t) * dlen);
   float lo = fminf(fminf(b0, b1), b2);
   uint32_t prim = f2u(q1.w);
   const uint32_t code = f2u(q2.w);
@@ -435,6 +437,7 @@ struct InstancePart {};
 template <>
 struct InstancePart<true> {
   f3 oo, od;          // the ray in the space of the instance it is in
+  float dlen;         // |od.x| + |od.y| + |od.z|: how far a unit of the ray's parameter goes there, at most
   uint32_t inst;      // that instance, kNoInstance at the top level
   uint32_t hit_inst;  // the instance of the closest hit so far
   int ret_sp;         // stack level at which the instance was entered
@@ -475,6 +478,7 @@ struct TraceStateT : InstancePart<INST> {
       this->ret_sp = 0;
       this->oo = o;
       this->od = d;
+      this->dlen = 1.0f;
     }
   }
   PT_HD bool wants_tri() const { return tg.bits != 0u; }
@@ -549,11 +553,12 @@ struct TraceStateT : InstancePart<INST> {
         this->od = mk3(q0.x * d.x + q0.y * d.y + q0.z * d.z, q1.x * d.x + q1.y * d.y + q1.z * d.z,
                        q2.x * d.x + q2.y * d.y + q2.z * d.z);
         set_ray(this->oo, this->od, q3.z);
+        this->dlen = fabsf(this->od.x) + fabsf(this->od.y) + fabsf(this->od.z);
         cur = StackEntry{f2u(q3.x), 0x80000000u};
         tg.bits = 0u;
         return false;
       }
-      int res = fast_triangle(q0, q1, q2, q3, this->oo, this->od, rmag, tmin, hit);
+      int res = fast_triangle(q0, q1, q2, q3, this->oo, this->od, rmag, tmin, hit, this->dlen);
       if (res == 2) res = watertight_item(sc, q1, q2, q3, this->oo, this->od, tmin, hit) ? 1 : 0;
       if (res == 1) this->hit_inst = this->inst;
       return res == 1 && any_hit;

@@ -1057,3 +1057,46 @@ def test_instances_under_rotation_and_uneven_scale(hostcheck, oracle):
         oracle.lib().orc_scene_set(None, 0, None, 0, None)
         hostcheck.hc_scene_cornell()
 
+
+def test_instanced_closed_mesh_does_not_leak(hostcheck):
+    """Rays aimed from inside a closed mesh at its vertices and along its edges never get out, whatever the
+    instance's scale: the ray keeps its parameter in object space, so its direction there is not a unit vector
+    and the fast test's error band has to grow with its length for points near an edge to reach the watertight test."""
+    rng = np.random.default_rng(41)
+    V = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    I = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.uint32)
+    edges = sorted({tuple(sorted((int(t[a]), int(t[b])))) for t in I for a, b in ((0, 1), (1, 2), (2, 0))})
+    try:
+        for scale in (1e-3, 0.03, 1.0, 40.0, 3e3):
+            a = rng.normal(size=(3, 3))
+            q, _ = np.linalg.qr(a)
+            m = (q * scale).astype(np.float32)
+            centre = rng.uniform(-0.5, 0.5, 3).astype(np.float32)
+            xf = np.concatenate([m, centre[:, None]], 1).reshape(1, 12).astype(np.float32)
+            assert hostcheck.hc_scene_instances(P(V), len(V), P(I, C.c_uint32), len(I), 1, P(xf)) == 1
+            W = V @ m.T + centre  # world-space vertices
+            targets = [W[i] for i in range(6)]
+            for i, j in edges:
+                for s in np.linspace(0.02, 0.98, 33):
+                    targets.append(W[i] * (1 - s) + W[j] * s)
+            targets = np.array(targets, np.float32)
+            o, d = [], []
+            for tgt in targets:
+                for _ in range(6):
+                    dirn = rng.normal(size=3)
+                    dirn /= np.linalg.norm(dirn)
+                    org = centre + dirn * scale * rng.uniform(0.0, 0.25)  # well inside the unit octahedron's image
+                    dd = tgt - org
+                    o.append(org)
+                    d.append(dd / np.linalg.norm(dd))
+            o, d = np.array(o, np.float32), np.array(d, np.float32)
+            prim, t, b1, b2, inst = _hc_trace_instanced(hostcheck, o, d)
+            assert (prim >= 0).all(), (scale, int((prim < 0).sum()), len(prim))
+            # and so does any other ray from the centre
+            dirs = rng.normal(size=(2000, 3)).astype(np.float32)
+            dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+            prim, _, _, _, _ = _hc_trace_instanced(hostcheck, np.tile(centre, (len(dirs), 1)), dirs)
+            assert (prim >= 0).all(), scale
+    finally:
+        hostcheck.hc_scene_cornell()
+
