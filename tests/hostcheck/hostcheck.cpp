@@ -212,6 +212,25 @@ void hc_guide_set(const float* regions8, int nr, const float* lobes8, int nl, co
   g_guiding = enabled;
 }
 
+// The per-record step of the device kernel that bins training statistics (pt_guiding.h: bin_train_record), run over
+// records in the layout guiding_map_train_samples returns: each gets the digest the capture would have written, then
+// goes through the same validation, assignment and fixed-point addends; torn[i] != 0 spoils record i's digest.
+void hc_bin_records(const float* rec10, int n, const float* bmin, const float* bmax, const int* res, const float* axes,
+                    const int* torn, long long* table) {
+  BinField f;
+  for (int k = 0; k < 3; ++k) { f.bmin[k] = bmin[k]; f.bmax[k] = bmax[k]; f.res[k] = res[k]; }
+  for (int i = 0; i < n; ++i) {
+    TrainRec r;
+    memcpy(&r, rec10 + 10 * (size_t)i, sizeof(r));
+    r.is_delta = (r.is_delta & 1u) | train_digest(r);
+    if (torn && torn[i]) r.contrib[1] += 1.0f;  // payload and digest no longer belong together
+    uint32_t bin;
+    long long add[kBinWords];
+    if (!bin_train_record(r, f, axes, bin, add)) continue;
+    for (int k = 0; k < kBinWords; ++k) table[(size_t)bin * kBinWords + k] += add[k];
+  }
+}
+
 // The two forms of the passes over a region's lobes (pt_guiding.h): one load per lobe and pass, or the region's
 // lobes loaded in batches.  lobes8: n <= 4 lobes in the snapshot layout; returns the chosen lobe and the mixture pdf
 // of direction wi in both forms.

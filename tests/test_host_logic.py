@@ -877,6 +877,28 @@ def test_binned_update_is_the_sample_update(pt):
         b.close()
 
 
+def test_device_binning_step_is_the_numpy_restatement(hostcheck, pt):
+    """bin_train_record, the per-record body of the GPU kernel, compiled for the host: over random records (some
+    outside the field, some of weight zero, some not numbers, some with a digest that does not match) the table is the
+    one tests/binning.py builds, word for word."""
+    import binning
+    rng = np.random.default_rng(9)
+    f = pt.GuidingField((-1, -1, 0), (1, 1, 2))
+    try:
+        f.update(_random_records(rng, 3000))  # move the axes off the coordinate directions
+        bmin, bmax, res, axes = f.layout()
+        rec = _random_records(rng, 5000)
+        rec[7, 0], rec[8, 2], rec[9, 7] = np.nan, np.inf, np.nan
+        torn = (rng.uniform(size=len(rec)) < 0.02).astype(np.int32)
+        table = np.zeros(int(np.prod(res)) * 6 * 8, np.int64)
+        hostcheck.hc_bin_records(P(rec), len(rec), P(bmin), P(bmax), P(res, C.c_int), P(axes), P(torn, C.c_int),
+                                 table.ctypes.data_as(C.POINTER(C.c_longlong)))
+        want = binning.bin_records(rec[torn == 0], bmin, bmax, res, axes)
+        assert np.array_equal(table, want) and table[7::8].sum() > 3000
+    finally:
+        f.close()
+
+
 def test_trainer_drops_records_that_are_not_numbers(pt):
     """A position or weight that is not a finite number trains nothing, on either path (the comparison against the
     field's bounds must not let a NaN through to the cell index)."""
