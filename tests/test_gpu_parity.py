@@ -568,6 +568,45 @@ def test_guided_shade_step_matches_oracle(gpu, oracle):
         L.guiding_set_enabled(0)
 
 
+@pytest.mark.parametrize("lobe", [0, 1, 2])
+def test_guided_branch_on_the_gpu_matches_quadrature(gpu, oracle, lobe):
+    """The GPU's guided diffuse branch (device lobe records, batched passes, hardware exp2 / log) against the float64
+    integral of the reference's selection rule: mean throughput factor of 400 000 shading steps at a floor point whose
+    region holds one lobe, 4.5 standard errors.  The oracle only looks the primitive up."""
+    import math_pins as mp
+    from test_oracle_golden import FLOOR_CASES, floor_case, GUIDE_PIN_LOBES, one_lobe_field
+    L = gpu.lib()
+    eye, point = FLOOR_CASES[0]
+    hit, eye32, d32, n, v = floor_case(oracle, eye, point)
+    mu, kappa, rgb = GUIDE_PIN_LOBES[lobe]
+    regions, lobes = one_lobe_field(mu, kappa, rgb)
+    want = mp.expected_guided_throughput_factor(n, v, lobes[0, 0:3].astype(np.float64), float(kappa), np.array(rgb, np.float64))
+    L.guiding_set_grid_res(1, 1, 1)
+    gpu.upload_snapshot(regions, lobes)
+    L.guiding_set_enabled(1)
+    try:
+        t0 = np.array([0.9, 0.7, 0.5])
+        N = 400000
+        recs = (HcRec * N)()
+        seeds = np.random.default_rng(21 + lobe).integers(0, 2 ** 63, N, dtype=np.uint64)
+        for i in range(N):
+            r = recs[i]
+            r.throughput[:] = t0.tolist()
+            r.origin[:] = eye32.tolist()
+            r.direction[:] = d32.tolist()
+            r.seed, r.rng_dim = int(seeds[i]), 2
+        out, _ = _gpu_shade(gpu)(recs, np.full(N, hit.prim, np.int32), np.full(N, hit.b1, np.float32), np.full(N, hit.b2, np.float32))
+        f = np.frombuffer(out, dtype=np.uint8).reshape(N, C.sizeof(HcRec))[:, :48].copy().view(np.float32).reshape(N, 12)
+        thr = f[:, 3:6].astype(np.float64)
+        mean, sem = thr.mean(0), thr.std(0) / np.sqrt(N)
+        assert (np.abs(mean - t0 * want) < 4.5 * sem + 2e-4 * t0 * want).all(), (mean, t0 * want, sem)
+        assert (sem < 0.02 * t0 * want).all()
+    finally:
+        L.guiding_set_enabled(0)
+        L.guiding_set_grid_res(1, 1, 1)
+        gpu.upload_snapshot(np.zeros((0, 8), np.float32), np.zeros((0, 8), np.float32))
+
+
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_guided_render_parity(gpu, oracle, pipeline):
     """Whole guided renders (field on, seeded synthetic snapshot) against the oracle's guided render:
