@@ -144,35 +144,44 @@ def vmf_pdf(mu, kappa, w):
     return kappa / (2.0 * PI * (1.0 - np.exp(-2.0 * kappa))) * np.exp(kappa * (w @ mu - 1.0))
 
 
-def expected_guided_throughput_factor(n, v, mu, kappa, lobe_rgb, n_theta=4000, n_phi=1024):
-    """E of the throughput factor at an opaque hit whose region holds ONE lobe (weight 1), with the field on
-    (optix_device.cu:596-658).  The diffuse branch (probability diff_prob) draws a direction w from the lobe, then
-    keeps it with probability a = p_g / (p_g + p_b), p_b = max(cos, 0) / pi -- the reference's rule, which is not an
-    unbiased one-sample MIS -- multiplying the throughput by kd * rgb * cos / (pi * p_g * diff_prob); otherwise it
-    takes a cosine-distributed direction with factor kd / diff_prob.  So the branch contributes
-        kd * Integral vmf(w) [ a rgb cos / (pi p_g) + (1 - a) ] dw,
-    evaluated on a (theta, phi) midpoint grid about mu; the specular branch is expected_throughput_factor's."""
+def expected_guided_throughput_factor(n, v, lobes, n_theta=4000, n_phi=1024):
+    """E of the throughput factor at an opaque hit whose region holds the given lobes [(mu, kappa, weight, rgb), ...],
+    with the field on (optix_device.cu:596-658).  The diffuse branch (probability diff_prob) picks lobe i with
+    probability weight_i / total (guiding_gpu.cuh:86-106), draws a direction w from it, then keeps w with
+    probability a = p_g / (p_g + p_b), where p_g is the pdf of the whole mixture at w and p_b = max(cos, 0) / pi --
+    the reference's rule, which is not an unbiased one-sample MIS -- multiplying the throughput by
+    kd * rgb_i * cos / (pi * p_g * diff_prob); otherwise it takes a cosine-distributed direction with factor
+    kd / diff_prob.  So the branch contributes
+        kd * Sum_i weight_i / total * Integral vmf_i(w) [ a rgb_i cos / (pi p_g) + (1 - a) ] dw,
+    each integral on a (theta, phi) grid about mu_i whose cells carry equal shares of lobe i's mass; the specular
+    branch is expected_throughput_factor's."""
     nov, spec_prob, diff_prob, kd = opaque_constants(n, v)
     e_unguided, _ = expected_throughput_factor(n, v, n_theta=3000, n_phi=720)
     e_spec_part = e_unguided - kd  # spec_prob * e_spec
-    mu = mu / np.linalg.norm(mu)
-    t = np.array([1.0, 0.0, 0.0]) if abs(mu[0]) < 0.9 else np.array([0.0, 1.0, 0.0])
-    t = t - mu * (t @ mu)
-    t /= np.linalg.norm(t)
-    b = np.cross(mu, t)
-    # put the grid where the lobe's mass is: uniform in the lobe's own cdf of cos(theta)
-    u = (np.arange(n_theta) + 0.5) / n_theta
-    ct = 1.0 + np.log(np.exp(-2.0 * kappa) + (1.0 - np.exp(-2.0 * kappa)) * u) / kappa  # inverse cdf: equal-mass rings
-    st = np.sqrt(np.maximum(0.0, 1.0 - ct * ct))
-    ph = (np.arange(n_phi) + 0.5) / n_phi * 2.0 * PI
-    w = st[:, None, None] * (np.cos(ph)[None, :, None] * t + np.sin(ph)[None, :, None] * b) + ct[:, None, None] * mu
-    cos = np.maximum(w @ n, 0.0)
-    p_g = vmf_pdf(mu, kappa, w)
-    p_b = cos / PI
-    a = p_g / (p_g + p_b)
-    inner = a[..., None] * lobe_rgb[None, None, :] * (cos / (PI * p_g))[..., None] + (1.0 - a)[..., None]
-    e_diff = kd * inner.mean((0, 1))  # every grid cell carries the same share of the lobe's mass
-    return e_spec_part + e_diff
+    total = sum(l[2] for l in lobes)
+    mus = [np.asarray(l[0], np.float64) / np.linalg.norm(l[0]) for l in lobes]
+
+    def mixture(w):
+        return sum(l[2] / total * vmf_pdf(m, l[1], w) for l, m in zip(lobes, mus))
+
+    e_diff = np.zeros(3)
+    for (_, kappa, weight, rgb), mu in zip(lobes, mus):
+        t = np.array([1.0, 0.0, 0.0]) if abs(mu[0]) < 0.9 else np.array([0.0, 1.0, 0.0])
+        t = t - mu * (t @ mu)
+        t /= np.linalg.norm(t)
+        b = np.cross(mu, t)
+        u = (np.arange(n_theta) + 0.5) / n_theta
+        ct = 1.0 + np.log(np.exp(-2.0 * kappa) + (1.0 - np.exp(-2.0 * kappa)) * u) / kappa  # inverse cdf: equal-mass rings
+        st = np.sqrt(np.maximum(0.0, 1.0 - ct * ct))
+        ph = (np.arange(n_phi) + 0.5) / n_phi * 2.0 * PI
+        w = st[:, None, None] * (np.cos(ph)[None, :, None] * t + np.sin(ph)[None, :, None] * b) + ct[:, None, None] * mu
+        cos = np.maximum(w @ n, 0.0)
+        p_g = mixture(w)
+        p_b = cos / PI
+        a = p_g / (p_g + p_b)
+        inner = a[..., None] * np.asarray(rgb, np.float64)[None, None, :] * (cos / (PI * p_g))[..., None] + (1.0 - a)[..., None]
+        e_diff += weight / total * inner.mean((0, 1))
+    return e_spec_part + kd * e_diff
 
 
 def chi2_threshold(dof):

@@ -568,19 +568,18 @@ def test_guided_shade_step_matches_oracle(gpu, oracle):
         L.guiding_set_enabled(0)
 
 
-@pytest.mark.parametrize("lobe", [0, 1, 2])
+@pytest.mark.parametrize("lobe", [0, 1, 2, 3])
 def test_guided_branch_on_the_gpu_matches_quadrature(gpu, oracle, lobe):
     """The GPU's guided diffuse branch (device lobe records, batched passes, hardware exp2 / log) against the float64
     integral of the reference's selection rule: mean throughput factor of 400 000 shading steps at a floor point whose
-    region holds one lobe, 4.5 standard errors.  The oracle only looks the primitive up."""
+    region holds one lobe or three, 4.5 standard errors.  The oracle only looks the primitive up."""
     import math_pins as mp
-    from test_oracle_golden import FLOOR_CASES, floor_case, GUIDE_PIN_LOBES, one_lobe_field
+    from test_oracle_golden import FLOOR_CASES, floor_case, GUIDE_PIN_LOBES, lobes_field, as_float32_lobes
     L = gpu.lib()
     eye, point = FLOOR_CASES[0]
     hit, eye32, d32, n, v = floor_case(oracle, eye, point)
-    mu, kappa, rgb = GUIDE_PIN_LOBES[lobe]
-    regions, lobes = one_lobe_field(mu, kappa, rgb)
-    want = mp.expected_guided_throughput_factor(n, v, lobes[0, 0:3].astype(np.float64), float(kappa), np.array(rgb, np.float64))
+    regions, lobes = lobes_field(GUIDE_PIN_LOBES[lobe])
+    want = mp.expected_guided_throughput_factor(n, v, as_float32_lobes(lobes))
     L.guiding_set_grid_res(1, 1, 1)
     gpu.upload_snapshot(regions, lobes)
     L.guiding_set_enabled(1)
