@@ -1242,6 +1242,47 @@ def test_adaptive_shared_one_rank_is_plain_adaptive(gpu):
     assert np.isfinite(out).all()
 
 
+def test_stopped_pixels_satisfy_the_noise_criterion(gpu):
+    """The stopping rule of optix_device.cu:1011-1049 recomputed outside the library: a pixel that stopped keeps the
+    statistics it stopped with, so its noise -- relative standard deviation of luminance, or of its own Bayer channel
+    if that is larger, from (sum, sum of squares, n) in float64 -- must lie below the threshold, and so must that of
+    every neighbour that stopped with it or before; pixels that never reached the minimum count never stop."""
+    import torch
+    w, h, spp, thr, mn = 96, 54, 256, 0.6, 32
+    dev = torch.device("cuda:0")
+    L = gpu.lib()
+    L.pt_set_adaptive_round(-32)
+    stats = torch.zeros(w * h * 8, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    gpu.render_adaptive_shared_device(stats, w, h, 0, spp, spp, 32, 9, thr, mn, reduce=None)
+    v = stats.view(h, w, 8).cpu().numpy().astype(np.float64)
+    s1, n, s2 = v[..., 0:3], v[..., 3], v[..., 4:7]
+    assert set(np.unique(n)) <= {32.0, 64.0, 128.0, 256.0} and n.min() >= mn
+    mean = s1 / n[..., None]
+    var = np.maximum(s2 - s1 * mean, 0.0) / (n[..., None] - 1.0)
+    lw = np.array([0.2126, 0.7152, 0.0722])
+    noise = np.sqrt(np.maximum(var @ lw, 0.0)) / np.maximum(mean @ lw, 1e-6)
+    yy, xx = np.mgrid[0:h, 0:w]
+    ch = np.where(yy % 2 == 0, np.where(xx % 2 == 0, 0, 1), np.where(xx % 2 == 0, 1, 2))  # pattern 0 (optix_device.cu:902-912)
+    mean_b = np.take_along_axis(mean, ch[..., None], 2)[..., 0]
+    var_b = np.take_along_axis(var, ch[..., None], 2)[..., 0]
+    noise = np.maximum(noise, np.sqrt(var_b) / np.maximum(mean_b, 1e-6))
+    stopped = n < spp
+    assert 0.2 < stopped.mean() < 0.98  # the render has both kinds of pixel
+    slack = 1e-4 * thr  # float32 statistics recomputed in float64
+    assert (noise[stopped] < thr + slack).all(), noise[stopped].max()
+    # neighbours that stopped no later than the pixel did held their final statistics when it was tested
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            nb_noise = np.roll(noise, (dy, dx), (0, 1))
+            nb_n = np.roll(n, (dy, dx), (0, 1))
+            inside = (yy - dy >= 0) & (yy - dy < h) & (xx - dx >= 0) & (xx - dx < w)
+            sel = stopped & inside & (nb_n <= n)
+            assert (nb_noise[sel] < thr + slack).all()
+    # and a pixel all of whose neighbourhood stayed noisy did not stop: where even the own noise is above the threshold
+    assert not (stopped & (noise >= thr + slack)).any()
+
+
 _SHARED_WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
