@@ -256,6 +256,12 @@ PT_EXPORT void pt_reset_kernel_stats(void);
 PT_EXPORT int pt_dbg_profile_counters(uint64_t* out64);
 /* Wall time of the device work of the last render call (HIP events around the whole loop). */
 PT_EXPORT double pt_last_render_ms(void);
+/* Chunks the last render split every pixel's sample range into (each chunk is a path slot with a random stream of
+ * its own, all in flight together).  Fixed-count renders of scenes that run fused: min(16, 8388608 / (w*h)), lowered
+ * until every chunk has 32 samples.  Scenes that run staged by default (trees beyond 4 MiB, instances) keep more
+ * in flight: min(16, 150994944 / (w*h)) chunks of as little as one sample, path state of 160 bytes per slot
+ * growing on demand up to a quarter of the free device memory.  strict_parity: 1. */
+PT_EXPORT int pt_last_render_chunks(void);
 
 /* Scene.  The built-in scene is the reference's Cornell box (optix_wrapper.cpp:379-489).
  * pt_scene_synthetic replaces it by the box plus a seeded grid of triangulated spheres

@@ -865,7 +865,12 @@ static void raygen(launch_ctx* L, uint32_t dst, uint64_t rays[2]) {
   int samples = L->sample_counts[dst];
   if (converge) {
     if (samples == 0) {
-      if (a->sample_begin != 0) seed ^= (uint64_t)(int64_t)a->sample_begin * 0x9E3779B97F4A7C15ULL;
+      if (a->sample_begin != 0) { /* a later sample range: a stream of its own, all 64 bits of its start mixed */
+        seed ^= (uint64_t)(int64_t)a->sample_begin * 0x9E3779B97F4A7C15ULL;
+        seed ^= seed >> 30; seed *= 0xBF58476D1CE4E5B9ULL;
+        seed ^= seed >> 27; seed *= 0x94D049BB133111EBULL;
+        seed ^= seed >> 31;
+      }
     } else {
       seed = L->seeds[dst];
     }

@@ -56,9 +56,17 @@ PT_HD uint64_t pixel_seed(int frame, uint32_t dst) {
 // Start of the PCG stream of a sample chunk that begins at global sample index `begin`.
 // begin == 0 is the reference's seed; later chunks get a decorrelated start so that
 // sample ranges rendered on different GPUs do not need each other's stream position.
+// The start is passed through a 64-bit finaliser: the first PCG output is a function of the state's high
+// bits alone, which pixel_seed leaves the same for every pixel of an image (the reference's first draw of a
+// stream varies by under 0.01 over a frame), and a render split into one-sample chunks takes only first draws.
 PT_HD uint64_t chunk_seed(int frame, uint32_t dst, int begin) {
   uint64_t s = pixel_seed(frame, dst);
-  if (begin != 0) s ^= (uint64_t)(int64_t)begin * 0x9E3779B97F4A7C15ULL;
+  if (begin != 0) {
+    s ^= (uint64_t)(int64_t)begin * 0x9E3779B97F4A7C15ULL;
+    s ^= s >> 30; s *= 0xBF58476D1CE4E5B9ULL;
+    s ^= s >> 27; s *= 0x94D049BB133111EBULL;
+    s ^= s >> 31;
+  }
   return s;
 }
 

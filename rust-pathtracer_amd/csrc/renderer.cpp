@@ -281,6 +281,59 @@ int max_chunks_for(size_t px) {
   return (int)std::max<size_t>(1, std::min<size_t>(16, target_slots / std::max<size_t>(px, 1)));
 }
 
+// The per-slot arrays for `chunks` slots per pixel (whatever they held is gone).
+constexpr size_t kSlotBytes = 9 * 16 + 4 * 4;  // nine 16-byte words, started, hit_inst and two queue entries
+void alloc_slots(State& s, int chunks) {
+  dev_free(s.st_o); dev_free(s.st_d); dev_free(s.st_s); dev_free(s.st_m); dev_free(s.acc); dev_free(s.hits);
+  dev_free(s.sh_o); dev_free(s.sh_d); dev_free(s.sh_c); dev_free(s.started); dev_free(s.hit_inst);
+  dev_free(s.queue[0]); dev_free(s.queue[1]);
+  s.max_chunks = chunks;
+  const size_t slots = (size_t)s.width * (size_t)s.height * (size_t)chunks;
+  s.st_o = dev_alloc<q4>(slots); s.st_d = dev_alloc<q4>(slots); s.st_s = dev_alloc<q4>(slots);
+  s.st_m = dev_alloc<u4>(slots); s.acc = dev_alloc<q4>(slots); s.hits = dev_alloc<q4>(slots);
+  s.sh_o = dev_alloc<q4>(slots); s.sh_d = dev_alloc<q4>(slots); s.sh_c = dev_alloc<q4>(slots);
+  s.started = dev_alloc<int>(slots);
+  s.hit_inst = dev_alloc<uint32_t>(slots);
+  s.queue[0] = dev_alloc<uint32_t>(slots);
+  s.queue[1] = dev_alloc<uint32_t>(slots);
+  if (s.acc2) {  // the adaptive renders' sum of squares is per slot too
+    dev_free(s.acc2);
+    s.acc2 = dev_alloc<q4>(slots);
+  }
+}
+
+// Chunks (slots per pixel) of a fixed-count render.  Scenes that run fused keep about 8 M slots in flight in
+// chunks of at least 32 samples.  Scenes that run staged (trees beyond 4 MiB, instances) do better the more of
+// their samples are in flight at once -- every launch is one bounce of every live path, so fewer, larger launches
+// leave fewer half-empty waves behind: up to 16 chunks of as little as one sample, 144 M slots (22 GB of the
+// GPU's 288) at most and never more than a quarter of what is free.  The state arrays grow when a render needs it.
+int chunks_for_render(State& s, int sample_count, bool strict) {
+  if (strict) return 1;
+  static const int chunk_override = getenv("PT_CHUNKS") ? atoi(getenv("PT_CHUNKS")) : 0;
+  static const size_t target_env = getenv("PT_TARGET_SLOTS") ? (size_t)atoll(getenv("PT_TARGET_SLOTS")) : 0;
+  static const int min_chunk_env = getenv("PT_MIN_CHUNK_SAMPLES") ? std::max(atoi(getenv("PT_MIN_CHUNK_SAMPLES")), 1) : 0;
+  const size_t px = std::max<size_t>((size_t)s.width * (size_t)s.height, 1);
+  const bool staged_scene = !s.borrowed && (s.scene.inst_records != nullptr || s.bvh_bytes > (size_t)(4u << 20));
+  const size_t target = target_env ? target_env : (staged_scene ? (size_t)144 << 20 : kTargetSlots);
+  const int min_chunk = min_chunk_env ? min_chunk_env : (staged_scene ? 1 : 32);
+  int chunks = (int)std::max<size_t>(1, std::min<size_t>(16, target / px));
+  if (chunk_override > 0) chunks = std::min(chunk_override, 16);
+  while (chunks > 1 && sample_count / chunks < min_chunk) --chunks;
+  if (s.borrowed) return std::min(chunks, s.max_chunks);
+  if (chunks > s.max_chunks) {
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipSetDevice(s.device));
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const size_t have = px * (size_t)s.max_chunks * kSlotBytes;
+    while (chunks > s.max_chunks && px * (size_t)chunks * kSlotBytes > (free_b + have) / 4) --chunks;
+    if (chunks > s.max_chunks) {
+      HIP_CHECK(hipStreamSynchronize(s.stream));
+      alloc_slots(s, chunks);
+    }
+  }
+  return chunks;
+}
+
 // optix_wrapper.cpp:784-920
 State* make_state(int W, int H, int device = -1) {
   State* s = new State();
@@ -299,15 +352,8 @@ State* make_state(int W, int H, int device = -1) {
   const size_t px = (size_t)W * (size_t)H;
   // A pixel's sample range may be rendered as several chunks side by side (one slot each);
   // state is sized for the most chunks a render of this resolution will use.
-  s->max_chunks = max_chunks_for(px);
-  const size_t slots = px * (size_t)s->max_chunks;
-  s->st_o = dev_alloc<q4>(slots); s->st_d = dev_alloc<q4>(slots); s->st_s = dev_alloc<q4>(slots);
-  s->st_m = dev_alloc<u4>(slots); s->acc = dev_alloc<q4>(slots); s->hits = dev_alloc<q4>(slots);
-  s->sh_o = dev_alloc<q4>(slots); s->sh_d = dev_alloc<q4>(slots); s->sh_c = dev_alloc<q4>(slots);
-  s->started = dev_alloc<int>(slots);
-  s->hit_inst = dev_alloc<uint32_t>(slots);
-  s->queue[0] = dev_alloc<uint32_t>(slots);
-  s->queue[1] = dev_alloc<uint32_t>(slots);
+  s->base_chunks = max_chunks_for(px);
+  alloc_slots(*s, s->base_chunks);
   s->counters = dev_alloc<uint32_t>(CNT_WORDS);
   s->ray_counters = dev_alloc<unsigned long long>(2);
   HIP_CHECK(hipMemset(s->ray_counters, 0, 2 * sizeof(unsigned long long)));
@@ -386,7 +432,7 @@ void resolve_timers(State& s) {
   s.timed.clear();
 }
 
-RenderParams make_params(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict) {
+RenderParams make_params(State& s, int sample_begin, int sample_count, int max_depth, int frame, bool strict, bool grow = true) {
   RenderParams p;
   memset(&p, 0, sizeof(p));
   p.scene = s.scene;
@@ -400,12 +446,8 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   p.sample_count = sample_count;
   p.strict = strict ? 1 : 0;
   p.npx = (uint32_t)((size_t)s.width * (size_t)s.height);
-  // chunks: strict mode replays one stream per pixel; converge mode splits the range while every
-  // chunk keeps at least 32 samples
-  static const int chunk_override = getenv("PT_CHUNKS") ? atoi(getenv("PT_CHUNKS")) : 0;
-  int chunks = strict ? 1 : (chunk_override > 0 ? std::min(chunk_override, s.max_chunks) : s.max_chunks);
-  while (chunks > 1 && sample_count / chunks < 32) --chunks;
-  p.chunks = std::max(chunks, 1);
+  // chunks: strict mode replays one stream per pixel; converge mode splits the range (chunks_for_render)
+  p.chunks = std::max(grow ? chunks_for_render(s, sample_count, strict) : 1, 1);
   p.chunk_spp = (sample_count + p.chunks - 1) / p.chunks;
   p.guiding = (g_guiding_enabled && s.guide_valid) ? 1 : 0;
   p.stack_depth = s.bvh_depth;
@@ -608,7 +650,7 @@ struct SharedStats {
 int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int frame, bool strict, float threshold,
                     int min_samples, const SharedStats* shared = nullptr) {
   ensure_adaptive(s);
-  RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict);
+  RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict, false);  // the chunks are set below
   const uint32_t npx = p.npx;
   if (shared && !s.shared_acc) {
     s.shared_acc = dev_alloc<q4>(npx);
@@ -631,7 +673,7 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
   while (first < min_samples && first < total) first = next_target(first);
   int chunks = 1;
   if (!strict) {
-    const int cap = g_adaptive_chunks > 0 ? std::min(g_adaptive_chunks, s.max_chunks) : s.max_chunks;
+    const int cap = g_adaptive_chunks > 0 ? std::min(g_adaptive_chunks, s.base_chunks) : s.base_chunks;
     const int step = local_target(std::min(round, total)), start = local_target(std::min(first, total));
     while (2 * chunks <= cap && step % (2 * chunks) == 0 && start % (2 * chunks) == 0 && step / (2 * chunks) >= 4) chunks *= 2;
   }
@@ -1187,7 +1229,7 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
   }
   s.width = w;
   s.height = h;
-  s.max_chunks = max_chunks_for(px);  // the same split into chunks as pt_render_accumulate_device ...
+  s.max_chunks = s.base_chunks = max_chunks_for(px);  // the same split into chunks as pt_render_accumulate_device ...
   const float eye[3] = {0.f, 3.f, 1.f}, look[3] = {0.f, 0.f, 1.f}, up[3] = {0.f, 0.f, 1.f};
   set_camera(s, eye, look, up, 45.f);
   RenderParams p = make_params(s, sample_begin, sample_count, max_depth, frame, false);
@@ -1335,6 +1377,7 @@ int pt_dbg_profile_counters(uint64_t* out64) {
   return read_profile_counters(reinterpret_cast<unsigned long long*>(out64));
 }
 double pt_last_render_ms(void) { return g_handle ? g_handle->last_render_ms : 0.0; }
+int pt_last_render_chunks(void) { return g_handle ? g_handle->last_chunks : 0; }
 
 void pt_scene_cornell(void) {
   g_scene = make_cornell();

@@ -38,7 +38,8 @@ struct State {
   int device = 0;
   int width = 0, height = 0;
   int num_cus = 256;
-  int max_chunks = 1;   // slots allocated per pixel
+  int max_chunks = 1;   // slots allocated per pixel (grows when a render of a large scene wants more)
+  int base_chunks = 1;  // what a renderer of this resolution starts with: the limit for adaptive renders
   int last_chunks = 1;  // chunks used by the most recent render
   hipStream_t stream = nullptr, copy_stream = nullptr;
   CameraView cam{};

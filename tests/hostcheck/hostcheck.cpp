@@ -291,6 +291,14 @@ void hc_shade(int n, HcRec* recs, const int* prim, const float* b1, const float*
 }
 
 // The per-pixel sample loop of the wavefront kernels, run sequentially per pixel.
+// First number drawn from the stream of the sample range that starts at `begin`, for pixels 0..n-1.
+void hc_first_draws(int frame, int begin, int n, float* out) {
+  for (int i = 0; i < n; ++i) {
+    uint64_t s = chunk_seed(frame, (uint32_t)i, begin);
+    out[i] = rnd(s);
+  }
+}
+
 void hc_render(int w, int h, int sample_begin, int sample_count, int max_depth, int frame, int strict, int nthreads,
                float* out_sum_rgb, unsigned long long* rays) {
   ensure();

@@ -515,6 +515,29 @@ def test_scene_triangles_checks_its_input(pt):
     L.pt_scene_cornell()
 
 
+def test_later_sample_ranges_start_streams_that_differ_between_pixels(hostcheck):
+    """The first number a PCG stream yields is a function of the high bits of its start.  The reference's per-pixel
+    seed (optix_device.cu:945-948) leaves those the same for every pixel of a frame: kept for the range that starts at
+    sample 0, since strict parity needs it.  Every later range (a chunk of a large scene's render can be one sample
+    long, a rank's share starts where the previous rank's ends) passes its start through a finaliser: first draws are
+    uniform over the pixels and unrelated between neighbours and between consecutive ranges."""
+    n = 200_000
+    out = np.zeros(n, np.float32)
+    hostcheck.hc_first_draws(3, 0, n, P(out))
+    assert out.max() - out.min() < 0.01  # the reference's stream start
+    draws = []
+    for begin in (1, 2, 3, 64, 4095):
+        hostcheck.hc_first_draws(3, begin, n, P(out))
+        draws.append(out.copy())
+        assert abs(out.mean() - 0.5) < 0.005 and abs(out.std() - 12 ** -0.5) < 0.005
+        hist = np.histogram(out, bins=64, range=(0, 1))[0]
+        assert np.abs(hist - n / 64).max() < 6 * (n / 64) ** 0.5
+        assert abs(np.corrcoef(out[:-1], out[1:])[0, 1]) < 0.01  # neighbouring pixels
+        assert abs(np.corrcoef(out[:-1920], out[1920:])[0, 1]) < 0.01  # one image row apart
+    for a, b in zip(draws[:-1], draws[1:]):
+        assert abs(np.corrcoef(a, b)[0, 1]) < 0.01
+
+
 def test_shard_ranges_partition_the_samples(pt):
     """pt_shard_range: the in-library shards of a render call are contiguous, disjoint, cover [0, spp) and differ
     by at most one sample; the setting itself needs no GPU."""

@@ -2,6 +2,7 @@
 profiles/pmc_traffic.json, which bench.py reads for the counter-derived fields of its roofline object.
 Run from the repository root after `make -C rust-pathtracer_amd asm`."""
 import csv
+import os
 import json
 import re
 import shutil
@@ -60,13 +61,19 @@ bench.py's HIP-event average for the fused kernel in the same run: {r['avg_launc
         "# one-GPU timings of the configurations (tools/configs.py)\n" + rd("configs.txt")
         + "\n# adaptive sampling at 1080p, 1024 spp maximum (tools/adaptive_time.py)\n" + rd("adaptive_time.txt")
         + "\n# demosaic at 4K, device-resident, steady state (tools/demosaic_time.py)\n"
-        + "".join(l for l in rd("demosaic_time.txt").splitlines(True) if "rep" in l))
+        + "".join(l for l in rd("demosaic_time.txt").splitlines(True) if "rep" in l)
+        + (("\n# configuration 4 whole on one GPU: 3840x2160 Bayer, 4096 spp, demosaic (tools/config4_full.py)\n" + rd("config4_full.txt"))
+           if os.path.exists(f"{SRC}/config4_full.txt") else ""))
     open("profiles/r02_bigscene.txt", "w").write(
         "# 12.8 M triangles as 2 500 spheres of 5 120, 3840x2160, 16 spp (tools/bigscene.py 2500 4 3840 2160 16);\n"
         "# pipe -1 = default choice, 1 = fused kernel reading the scene from global memory, 0 = staged kernels\n" + rd("bigscene.txt")
         + "\n# per-kernel times, staged pipeline (tools/bigscene_stats.py)\n" + rd("bigscene_stats.txt")
         + "\n# the same triangle count as 40 000 spheres of 320 (the scene of the GPU test; tools/bigscene.py 40000 2 3840 2160 16)\n"
-        + rd("bigscene_40000.txt"))
+        + rd("bigscene_40000.txt")
+        + (("\n# the room and one 320-triangle sphere placed 40 000 times (two-level tree, staged kernels; INSTANCED=1 tools/bigscene_spp.py 40000 2 3840 2160 16)\n"
+            + rd("bigscene_instanced.txt")) if os.path.exists(f"{SRC}/bigscene_instanced.txt") else "")
+        + (("\n# section counters of the traversal kernels at 4 spp (profiling build; tools/sections_staged.py 2500 4 3840 2160 4)\n"
+            + rd("sections_staged.txt")) if os.path.exists(f"{SRC}/sections_staged.txt") else ""))
 
     # static issue cost of the fused kernel's instruction mix
     isa = subprocess.run([sys.executable, "tools/isa_cost.py", "rust-pathtracer_amd/build/pt_kernels.s",
