@@ -235,6 +235,12 @@ PT_EXPORT int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, 
 
 /* src/main.rs:420-435: write w*h RGB f32 (times exposure) as a scanline OpenEXR file. */
 PT_EXPORT int pt_write_exr(const char* path, int w, int h, const float* rgb, float exposure);
+/* Display copy of a render as a PNG: rgb * exposure clamped to [0, 1], sRGB transfer function, rounded to the
+ * nearest of 2^bits - 1 codes; bits = 8 or 16.  The reference ships such a file (pt.png) and still lists an image
+ * encoder in Cargo.toml:8-13, but its writer is gone from src/main.rs; arguments follow save_exr_linear
+ * (src/main.rs:420-435).  Returns 0, -1 for bad arguments, -2 for an image beyond 2 GiB of samples, -3 / -4 when
+ * compression or the file fails. */
+PT_EXPORT int pt_write_png(const char* path, int w, int h, const float* rgb, float exposure, int bits);
 /* Minimal reader for files written by pt_write_exr (tests). Returns 0 on success. */
 PT_EXPORT int pt_read_exr(const char* path, int* w, int* h, float* rgb_or_null, size_t capacity_floats);
 

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
   bool guiding = false;
   uint32_t update_interval = 1;
   int grid_res[3] = {1, 1, 1};
-  std::string out_rgb = "pt.exr", out_bayer = "pt_bayer.exr", v;
+  std::string out_rgb = "pt.exr", out_bayer = "pt_bayer.exr", out_png, v;  // --png=FILE: an 8-bit sRGB copy of the RGB render
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     if (!strcmp(a, "--guiding")) guiding = true;
@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
     }
     else if (arg_value(a, "--out", v)) out_rgb = v;
     else if (arg_value(a, "--out-bayer", v)) out_bayer = v;
+    else if (arg_value(a, "--png", v)) out_png = v;
     else { fprintf(stderr, "unknown argument %s\n", a); return 2; }
   }
   const float scene_min[3] = {-1.0f, -1.0f, 0.0f}, scene_max[3] = {1.0f, 1.0f, 2.0f};
@@ -91,6 +92,10 @@ int main(int argc, char** argv) {
   printf("Exposure multiplier=%.6f\n", exposure);
   if (pt_write_exr(out_rgb.c_str(), w, h, rgb, exposure) == 0) printf("Saved %s (render %.3fs)\n", out_rgb.c_str(), t_rgb);
   else fprintf(stderr, "Failed to save %s\n", out_rgb.c_str());
+  if (!out_png.empty()) {
+    if (pt_write_png(out_png.c_str(), w, h, rgb, exposure, 8) == 0) printf("Saved %s\n", out_png.c_str());
+    else fprintf(stderr, "Failed to save %s\n", out_png.c_str());
+  }
 
   const auto t2 = clk::now();
   std::vector<float> demosaiced((size_t)w * h * 3);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "pt_demosaic_f32": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "pt_demosaic_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pt_write_exr": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _fp, C.c_float]),
+    "pt_write_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _fp, C.c_float, C.c_int]),
     "pt_read_exr": (C.c_int, [C.c_char_p, _ip, _ip, _fp, C.c_size_t]),
     "pt_get_ray_counts": (None, [_u64p, _u64p]),
     "pt_reset_ray_counts": (None, []),
@@ -246,6 +247,12 @@ def demosaic(raw, pattern=0, algo=0):
     if rc != 0:
         raise RuntimeError(f"pt_demosaic_f32 returned {rc}")
     return out
+
+
+def write_png(path, rgb, exposure=1.0, bits=8):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    h, w, _ = rgb.shape
+    return lib().pt_write_png(path.encode(), w, h, _f(rgb), exposure, bits)
 
 
 def write_exr(path, rgb, exposure=1.0):

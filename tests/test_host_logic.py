@@ -457,6 +457,66 @@ def test_exr_round_trip(pt, tmp_path):
     assert pt.lib().pt_write_exr(b"/nonexistent_dir/x.exr", 1, 1, P(np.zeros(3, np.float32)), 1.0) == -1
 
 
+def _decode_png(raw):
+    """A PNG decoder for the files under test: chunks with checked CRCs, one zlib stream, filters 0-2, RGB 8/16."""
+    import struct
+    import zlib
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(raw):
+        n, kind = struct.unpack(">I4s", raw[at:at + 8])
+        data = raw[at + 8:at + 8 + n]
+        assert struct.unpack(">I", raw[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + data)
+        chunks.append((kind, data))
+        at += 12 + n
+    assert chunks[0][0] == b"IHDR" and chunks[-1] == (b"IEND", b"")
+    w, h, bits, colour, comp, flt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (colour, comp, flt, lace) == (2, 0, 0, 0) and bits in (8, 16)
+    assert (b"sRGB", b"\x00") in chunks
+    data = zlib.decompress(b"".join(d for k, d in chunks if k == b"IDAT"))
+    row = w * 3 * bits // 8
+    assert len(data) == (row + 1) * h
+    out = np.zeros((h, row), np.uint8)
+    prev = np.zeros(row, np.uint8)
+    for y in range(h):
+        line = np.frombuffer(data, np.uint8, row, y * (row + 1) + 1)
+        f = data[y * (row + 1)]
+        assert f in (0, 2)
+        prev = line if f == 0 else (line + prev).astype(np.uint8)
+        out[y] = prev
+    if bits == 16:
+        return (out[:, 0::2].astype(np.uint16) << 8 | out[:, 1::2]).reshape(h, w, 3), bits
+    return out.reshape(h, w, 3), bits
+
+
+def test_png_export_is_the_srgb_encoding_of_the_render(pt, tmp_path):
+    """The display copy: value * exposure clamped to [0, 1], sRGB transfer (IEC 61966-2-1) in float64 here, nearest
+    code of 8 or 16 bits; negative values and NaN come out black, everything from 1 up white.  The reference's
+    own pt.png was written by code no longer in its tree, so the format is checked, not that file's bytes."""
+    rng = np.random.default_rng(3)
+    for (h, w) in [(1, 1), (5, 7), (54, 96)]:
+        img = rng.uniform(0, 1.3, (h, w, 3)).astype(np.float32)
+        img.ravel()[:: 11] = rng.uniform(0, 0.01, img.ravel()[:: 11].shape)  # the linear toe
+        if img.size > 8:
+            img.ravel()[1], img.ravel()[2], img.ravel()[3] = -0.5, np.nan, np.inf
+        for bits, exposure in ((8, 1.0), (16, 1.0), (8, 0.5)):
+            path = str(tmp_path / f"t_{w}x{h}_{bits}.png")
+            assert pt.write_png(path, img, exposure, bits) == 0
+            codes, got_bits = _decode_png(open(path, "rb").read())
+            assert got_bits == bits and codes.shape == (h, w, 3)
+            v = np.nan_to_num(img.astype(np.float64) * exposure, nan=0.0, posinf=1.0).clip(0.0, 1.0)
+            enc = np.where(v <= 0.0031308, 12.92 * v, 1.055 * np.power(v, 1 / 2.4) - 0.055)
+            want = enc * (2 ** bits - 1)
+            # float32 arithmetic in the writer: the code is the nearest one except within 2e-3 of a code of a tie
+            assert np.abs(codes.astype(np.float64) - want).max() < 0.5 + (2e-3 if bits == 8 else 0.05)
+            if img.size > 8:
+                assert tuple(codes.ravel()[1:4]) == (0, 0, 2 ** bits - 1)
+    L = pt.lib()
+    assert L.pt_write_png(b"/nonexistent_dir/x.png", 1, 1, P(np.zeros(3, np.float32)), 1.0, 8) == -4
+    assert L.pt_write_png(str(tmp_path / "x.png").encode(), 1, 1, P(np.zeros(3, np.float32)), 1.0, 12) == -1
+    assert L.pt_write_png(str(tmp_path / "x.png").encode(), 0, 1, P(np.zeros(3, np.float32)), 1.0, 8) == -1
+
+
 def test_exr_reader_rejects_damaged_files(pt, tmp_path):
     """Truncated or corrupted files: an error code, never a read outside the file."""
     L = pt.lib()
