@@ -8,7 +8,8 @@
 namespace pt {
 
 // Device counters (uint32 words) shared by the wavefront kernels.
-enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_SHADOW = 2, CNT_WORDS = 8 };
+// CNT_EXTEND / CNT_OCCLUDE: how much of the queue the waves of k_extend / k_occlude have taken so far (k_generate clears both)
+enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_SHADOW = 2, CNT_EXTEND = 3, CNT_OCCLUDE = 4, CNT_WORDS = 8 };
 
 // Everything a wavefront kernel needs, passed by value (lives in the kernarg segment).
 struct RenderParams {

@@ -220,6 +220,10 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
   const uint32_t n = p.counters[qin];
   const uint32_t* q_in = p.queue[qin];
   uint32_t* q_out = p.queue[qin ^ 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the traversal kernels that follow start at the front of their queues
+    p.counters[CNT_EXTEND] = 0u;
+    p.counters[CNT_OCCLUDE] = 0u;
+  }
   for (uint32_t base = blockIdx.x * (blockDim.x * ITEMS); base < n; base += gridDim.x * (blockDim.x * ITEMS)) {
     bool keep[ITEMS];
     uint32_t pixel[ITEMS];
@@ -270,6 +274,31 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
 // their rays they take the next ones from the range while the rest keep traversing.  Each iteration
 // advances every busy lane by one step: a child-node visit or a triangle test.
 
+//
+// The ranges are not fixed per wave: a wave takes the next `grab` entries from a counter all waves share whenever
+// it has used up what it held, so a wave whose rays were short goes on where the others have not been yet and
+// the launch ends when the queue does, not when the wave with the longest share does.
+struct QueueRange {
+  uint32_t cursor = 0u, end = 0u;  // the same on every lane
+  bool more = true;
+};
+__device__ __forceinline__ uint32_t grab_size(uint32_t n) {
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t g = (n / (nwaves * 4u)) & ~63u;  // several grabs per wave, whole waves' worth of rays
+  return g < 64u ? 64u : (g > 2048u ? 2048u : g);
+}
+__device__ __forceinline__ void take_range(QueueRange& r, uint32_t* counter, uint32_t grab, uint32_t n) {
+  uint32_t b = 0u;
+  if ((threadIdx.x & 63u) == 0u) b = atomicAdd(counter, grab);
+  b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+  if (b >= n) {
+    r.more = false;
+  } else {
+    r.cursor = b;
+    r.end = b + grab < n ? b + grab : n;
+  }
+}
+
 // INST: the scene is made of instances (pt_bvh.h: TraceStateT<true>); the hit's instance goes to hit_inst.
 template <bool INST>
 __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
@@ -278,10 +307,8 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
   LdsStack st = lds_stack();
   if (blockIdx.x == 0 && threadIdx.x == 0) p.ray_counters[0] += n;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t per = (n + nwaves - 1u) / nwaves;
-  uint32_t cursor = wave * per;  // the same on every lane
-  const uint32_t end = cursor + per < n ? cursor + per : n;
+  const uint32_t grab = grab_size(n);
+  QueueRange r;
   TraceStateT<INST> ts;
   ts.finish();
   f3 ro = mk3(0.f), rd = mk3(0.f);
@@ -290,10 +317,12 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
   for (;;) {
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
-    if (cursor < end && (n_idle >= (uint32_t)p.refill_lanes || n_idle == 64u)) {
+    const bool refill = n_idle >= (uint32_t)p.refill_lanes || n_idle == 64u;
+    if (refill && r.more && r.cursor >= r.end) take_range(r, &p.counters[CNT_EXTEND], grab, n);
+    if (r.cursor < r.end && refill) {
       if (idx == 0xffffffffu) {
-        const uint32_t i = cursor + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-        if (i < end) {
+        const uint32_t i = r.cursor + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (i < r.end) {
           idx = i;
           const uint32_t pixel = queue[i];
           const q4 a = p.st_o[pixel], b = p.st_d[pixel];
@@ -302,7 +331,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
           ts.begin(p.scene, ro, rd, 1e16f, 0u);
         }
       }
-      cursor += n_idle;
+      r.cursor += n_idle;
     } else if (n_idle == 64u) {
       break;
     }
@@ -376,10 +405,8 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   LdsStack st = lds_stack();
   if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[q ^ 1] = 0u;  // the queue the next generate pass appends to
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t per = (n + nwaves - 1u) / nwaves;
-  uint32_t cursor = wave * per;
-  const uint32_t end = cursor + per < n ? cursor + per : n;
+  const uint32_t grab = grab_size(n);
+  QueueRange r;
   uint32_t traced = 0;
   TraceStateT<INST> ts;
   ts.finish();
@@ -389,10 +416,12 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   for (;;) {  // same scheme as k_extend; records without a shadow ray (tmax < 0) finish at once
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
-    if (cursor < end && (n_idle >= (uint32_t)p.refill_lanes || n_idle == 64u)) {
+    const bool refill = n_idle >= (uint32_t)p.refill_lanes || n_idle == 64u;
+    if (refill && r.more && r.cursor >= r.end) take_range(r, &p.counters[CNT_OCCLUDE], grab, n);
+    if (r.cursor < r.end && refill) {
       if (idx == 0xffffffffu) {
-        const uint32_t i = cursor + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-        if (i < end) {
+        const uint32_t i = r.cursor + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (i < r.end) {
           const q4 o = p.sh_o[i];
           if (o.w >= 0.0f) {
             idx = i;
@@ -404,7 +433,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
           }
         }
       }
-      cursor += n_idle;
+      r.cursor += n_idle;
     } else if (n_idle == 64u) {
       break;
     }
