@@ -27,6 +27,7 @@ struct RenderParams {
   int stack_depth;                 // traversal stack entries per lane
   uint32_t scene_nodes;            // number of BVH nodes
   int scene_in_lds;                // stage a small scene in LDS (fused kernel)
+  int shared_ranges;               // ... their waves take queue ranges from a shared counter (long rays) / hold one fixed share each
   int refill_lanes;                // staged traversal kernels: idle lanes that trigger taking new rays
   int defer_shadow;                // fused kernel: queue shadow rays per wave and trace them 64 at a time
   // per-pixel path state, SoA of 16-byte words

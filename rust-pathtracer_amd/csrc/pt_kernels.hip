@@ -275,22 +275,38 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
 // advances every busy lane by one step: a child-node visit or a triangle test.
 
 //
-// The ranges are not fixed per wave: a wave takes the next `grab` entries from a counter all waves share whenever
-// it has used up what it held, so a wave whose rays were short goes on where the others have not been yet and
-// the launch ends when the queue does, not when the wave with the longest share does.
+// Scenes whose rays are long (trees beyond the caches, RenderParams::shared_ranges) do not fix the ranges per
+// wave: a wave that has used up what it held takes the next `grab` entries from a counter all waves share, so a wave
+// whose rays were short goes on where the others have not been yet and the launch ends when the queue does, not
+// when the wave with the slowest share does.  Where rays are cheap the same-address atomics would be the kernel
+// (2.3 times slower on the built-in scene), and every wave gets one contiguous share beforehand.
 struct QueueRange {
-  uint32_t cursor = 0u, end = 0u;  // the same on every lane
-  bool more = true;
+  uint32_t cursor, end;  // the same on every lane
+  uint32_t grab;
+  bool more;
 };
-__device__ __forceinline__ uint32_t grab_size(uint32_t n) {
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t g = (n / (nwaves * 4u)) & ~63u;  // several grabs per wave, whole waves' worth of rays
-  return g < 64u ? 64u : (g > 2048u ? 2048u : g);
+__device__ __forceinline__ QueueRange first_range(uint32_t n, bool shared) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  QueueRange r;
+  if (shared) {
+    const uint32_t g = (n / (nwaves * 4u)) & ~63u;  // several ranges per wave, whole waves' worth of rays
+    r.grab = g < 64u ? 64u : (g > 2048u ? 2048u : g);
+    r.cursor = r.end = 0u;
+    r.more = true;
+  } else {
+    const uint32_t per = (n + nwaves - 1u) / nwaves;
+    r.grab = 0u;
+    r.cursor = wave * per;
+    r.end = r.cursor + per < n ? r.cursor + per : n;
+    r.more = false;
+  }
+  return r;
 }
-__device__ __forceinline__ void take_range(QueueRange& r, uint32_t* counter, uint32_t grab, uint32_t n) {
+__device__ __forceinline__ void take_range(QueueRange& r, uint32_t* counter, uint32_t n) {
   uint32_t b = 0u;
-  if ((threadIdx.x & 63u) == 0u) b = atomicAdd(counter, grab);
+  if ((threadIdx.x & 63u) == 0u) b = atomicAdd(counter, r.grab);
   b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+  const uint32_t grab = r.grab;
   if (b >= n) {
     r.more = false;
   } else {
@@ -307,8 +323,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
   LdsStack st = lds_stack();
   if (blockIdx.x == 0 && threadIdx.x == 0) p.ray_counters[0] += n;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t grab = grab_size(n);
-  QueueRange r;
+  QueueRange r = first_range(n, p.shared_ranges != 0);
   TraceStateT<INST> ts;
   ts.finish();
   f3 ro = mk3(0.f), rd = mk3(0.f);
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(256) k_extend(RenderParams p, int q) {
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     const bool refill = n_idle >= (uint32_t)p.refill_lanes || n_idle == 64u;
-    if (refill && r.more && r.cursor >= r.end) take_range(r, &p.counters[CNT_EXTEND], grab, n);
+    if (refill && r.more && r.cursor >= r.end) take_range(r, &p.counters[CNT_EXTEND], n);
     if (r.cursor < r.end && refill) {
       if (idx == 0xffffffffu) {
         const uint32_t i = r.cursor + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -405,8 +420,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   LdsStack st = lds_stack();
   if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[q ^ 1] = 0u;  // the queue the next generate pass appends to
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t grab = grab_size(n);
-  QueueRange r;
+  QueueRange r = first_range(n, p.shared_ranges != 0);
   uint32_t traced = 0;
   TraceStateT<INST> ts;
   ts.finish();
@@ -417,7 +431,7 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     const bool refill = n_idle >= (uint32_t)p.refill_lanes || n_idle == 64u;
-    if (refill && r.more && r.cursor >= r.end) take_range(r, &p.counters[CNT_OCCLUDE], grab, n);
+    if (refill && r.more && r.cursor >= r.end) take_range(r, &p.counters[CNT_OCCLUDE], n);
     if (r.cursor < r.end && refill) {
       if (idx == 0xffffffffu) {
         const uint32_t i = r.cursor + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));

@@ -192,6 +192,7 @@ void describe_scene(State& s, const BvhBuildResult& bvh) {
   s.bvh_depth = std::max(bvh.depth, 1);
   s.num_nodes = (int)bvh.nodes.size();
   s.bvh_bytes = bvh.nodes.size() * sizeof(BvhNode) + bvh.tris.size() * sizeof(q4);
+  s.num_instances = (int)(bvh.inst_records.size() / 6);
   s.scene_version = g_scene_version;
 }
 
@@ -458,6 +459,9 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
     p.defer_shadow = g_defer_shadow;
     static const int refill = getenv("PT_REFILL_LANES") ? atoi(getenv("PT_REFILL_LANES")) : 16;
     p.refill_lanes = std::min(std::max(refill, 1), 64);
+    static const int shared_env = getenv("PT_SHARED_RANGES") ? atoi(getenv("PT_SHARED_RANGES")) : -1;
+    // long rays: a tree beyond the caches, or a thousand instances (whose tree is small however much it stands for)
+    p.shared_ranges = shared_env >= 0 ? shared_env : ((s.bvh_bytes > (size_t)(4u << 20) || s.num_instances >= 1000) ? 1 : 0);
   }
   p.st_o = s.st_o; p.st_d = s.st_d; p.st_s = s.st_s; p.st_m = s.st_m; p.acc = s.acc;
   p.started = s.started;

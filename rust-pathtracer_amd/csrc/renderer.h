@@ -54,6 +54,7 @@ struct State {
   SceneView scene{};
   int bvh_depth = 1, num_nodes = 0;
   size_t bvh_bytes = 0;
+  int num_instances = 0;
   uint64_t scene_version = 0;
 
   // path state / queues
