@@ -288,9 +288,9 @@ struct QueueRange {
 __device__ __forceinline__ QueueRange first_range(uint32_t n, bool shared) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   QueueRange r;
-  if (shared) {
-    const uint32_t g = (n / (nwaves * 4u)) & ~63u;  // several ranges per wave, whole waves' worth of rays
-    r.grab = g < 64u ? 64u : (g > 2048u ? 2048u : g);
+  const uint32_t g = (n / (nwaves * 4u)) & ~63u;  // several ranges per wave, whole waves' worth of rays
+  if (shared && g >= 512u) {  // shorter ranges cost more in atomics than the even finish gains
+    r.grab = g > 2048u ? 2048u : g;
     r.cursor = r.end = 0u;
     r.more = true;
   } else {

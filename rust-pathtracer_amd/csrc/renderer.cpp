@@ -303,10 +303,15 @@ void alloc_slots(State& s, int chunks) {
   }
 }
 
+// Trees up to this size run fused by default, larger ones staged (measured on spheres in the room at 1080p, 256
+// samples: 1.4 MiB fused 4.9 against staged 4.5 Grays/s, 2.7 MiB 3.5 against 4.0).
+constexpr size_t kFusedTreeBytes = (size_t)2u << 20;
+bool staged_by_default(const State& s) { return s.scene.inst_records != nullptr || s.bvh_bytes > kFusedTreeBytes; }
+
 // Chunks (slots per pixel) of a fixed-count render.  Scenes that run fused keep about 8 M slots in flight in
-// chunks of at least 32 samples.  Scenes that run staged (trees beyond 4 MiB, instances) do better the more of
+// chunks of at least 32 samples.  Scenes that run staged (larger trees, instances) do better the more of
 // their samples are in flight at once -- every launch is one bounce of every live path, so fewer, larger launches
-// leave fewer half-empty waves behind: up to 16 chunks of as little as one sample, 144 M slots (22 GB of the
+// leave fewer half-empty waves behind: up to 64 chunks of as little as one sample, 144 M slots (22 GB of the
 // GPU's 288) at most and never more than a quarter of what is free.  The state arrays grow when a render needs it.
 int chunks_for_render(State& s, int sample_count, bool strict) {
   if (strict) return 1;
@@ -314,11 +319,12 @@ int chunks_for_render(State& s, int sample_count, bool strict) {
   static const size_t target_env = getenv("PT_TARGET_SLOTS") ? (size_t)atoll(getenv("PT_TARGET_SLOTS")) : 0;
   static const int min_chunk_env = getenv("PT_MIN_CHUNK_SAMPLES") ? std::max(atoi(getenv("PT_MIN_CHUNK_SAMPLES")), 1) : 0;
   const size_t px = std::max<size_t>((size_t)s.width * (size_t)s.height, 1);
-  const bool staged_scene = !s.borrowed && (s.scene.inst_records != nullptr || s.bvh_bytes > (size_t)(4u << 20));
+  const bool staged_scene = !s.borrowed && staged_by_default(s);
+  const int most = staged_scene ? 64 : 16;
   const size_t target = target_env ? target_env : (staged_scene ? (size_t)144 << 20 : kTargetSlots);
   const int min_chunk = min_chunk_env ? min_chunk_env : (staged_scene ? 1 : 32);
-  int chunks = (int)std::max<size_t>(1, std::min<size_t>(16, target / px));
-  if (chunk_override > 0) chunks = std::min(chunk_override, 16);
+  int chunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)most, target / px));
+  if (chunk_override > 0) chunks = std::min(chunk_override, most);
   while (chunks > 1 && sample_count / chunks < min_chunk) --chunks;
   if (s.borrowed) return std::min(chunks, s.max_chunks);
   if (chunks > s.max_chunks) {
@@ -460,7 +466,8 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
     static const int refill = getenv("PT_REFILL_LANES") ? atoi(getenv("PT_REFILL_LANES")) : 16;
     p.refill_lanes = std::min(std::max(refill, 1), 64);
     static const int shared_env = getenv("PT_SHARED_RANGES") ? atoi(getenv("PT_SHARED_RANGES")) : -1;
-    // long rays: a tree beyond the caches, or a thousand instances (whose tree is small however much it stands for)
+    // long rays: a tree beyond the caches, or a thousand instances (whose tree is small however much it stands for);
+    // the kernels use it in launches large enough for ranges of 512 rays and more
     p.shared_ranges = shared_env >= 0 ? shared_env : ((s.bvh_bytes > (size_t)(4u << 20) || s.num_instances >= 1000) ? 1 : 0);
   }
   p.st_o = s.st_o; p.st_d = s.st_d; p.st_s = s.st_s; p.st_m = s.st_m; p.acc = s.acc;
@@ -506,7 +513,7 @@ struct RenderLoop {
     // Small scenes are instruction-bound: keep paths in registers (fused).  Scenes whose BVH lives in
     // HBM are latency-bound: the lean staged kernels run at twice the occupancy and win.
     const int chosen = pipeline();
-    fused = chosen >= 0 ? chosen == PT_PIPELINE_FUSED : s.bvh_bytes <= (size_t)(4u << 20);
+    fused = chosen >= 0 ? chosen == PT_PIPELINE_FUSED : s.bvh_bytes <= kFusedTreeBytes;
     // Auto mode only: once few paths are left, staged iterations (one bounce, four launches) are mostly
     // launch overhead; the fused kernel then finishes the stragglers, many bounces per launch.  Both
     // pipelines work on the same state and give the same bits.
