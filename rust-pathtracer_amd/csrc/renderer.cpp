@@ -303,6 +303,24 @@ void alloc_slots(State& s, int chunks) {
   }
 }
 
+// The state arrays hold `chunks` slots per pixel after this, or as many as a quarter of the free memory allows.
+int fit_chunks(State& s, int chunks) {
+  if (s.borrowed) return std::min(chunks, s.max_chunks);
+  if (chunks > s.max_chunks) {
+    const size_t px = std::max<size_t>((size_t)s.width * (size_t)s.height, 1);
+    size_t free_b = 0, total_b = 0;
+    HIP_CHECK(hipSetDevice(s.device));
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const size_t have = px * (size_t)s.max_chunks * kSlotBytes;
+    while (chunks > s.max_chunks && px * (size_t)chunks * kSlotBytes > (free_b + have) / 4) --chunks;
+    if (chunks > s.max_chunks) {
+      HIP_CHECK(hipStreamSynchronize(s.stream));
+      alloc_slots(s, chunks);
+    }
+  }
+  return chunks;
+}
+
 // Trees up to this size run fused by default, larger ones staged (measured on spheres in the room at 1080p, 256
 // samples: 1.4 MiB fused 4.9 against staged 4.5 Grays/s, 2.7 MiB 3.5 against 4.0).
 constexpr size_t kFusedTreeBytes = (size_t)2u << 20;
@@ -326,19 +344,7 @@ int chunks_for_render(State& s, int sample_count, bool strict) {
   int chunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)most, target / px));
   if (chunk_override > 0) chunks = std::min(chunk_override, most);
   while (chunks > 1 && sample_count / chunks < min_chunk) --chunks;
-  if (s.borrowed) return std::min(chunks, s.max_chunks);
-  if (chunks > s.max_chunks) {
-    size_t free_b = 0, total_b = 0;
-    HIP_CHECK(hipSetDevice(s.device));
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    const size_t have = px * (size_t)s.max_chunks * kSlotBytes;
-    while (chunks > s.max_chunks && px * (size_t)chunks * kSlotBytes > (free_b + have) / 4) --chunks;
-    if (chunks > s.max_chunks) {
-      HIP_CHECK(hipStreamSynchronize(s.stream));
-      alloc_slots(s, chunks);
-    }
-  }
-  return chunks;
+  return fit_chunks(s, chunks);
 }
 
 // optix_wrapper.cpp:784-920
@@ -661,8 +667,7 @@ struct SharedStats {
 int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int frame, bool strict, float threshold,
                     int min_samples, const SharedStats* shared = nullptr) {
   ensure_adaptive(s);
-  RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict, false);  // the chunks are set below
-  const uint32_t npx = p.npx;
+  const uint32_t npx = (uint32_t)((size_t)s.width * (size_t)s.height);
   if (shared && !s.shared_acc) {
     s.shared_acc = dev_alloc<q4>(npx);
     s.shared_acc2 = dev_alloc<q4>(npx);
@@ -684,10 +689,18 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
   while (first < min_samples && first < total) first = next_target(first);
   int chunks = 1;
   if (!strict) {
-    const int cap = g_adaptive_chunks > 0 ? std::min(g_adaptive_chunks, s.base_chunks) : s.base_chunks;
+    // scenes that run staged keep more slots in flight (chunks_for_render); a function of scene and resolution,
+    // not of what earlier renders left allocated, so a render gives the same result whatever came before it
+    const bool staged_scene = !s.borrowed && staged_by_default(s);
+    const int room = staged_scene ? (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)144 << 20) / std::max<uint32_t>(npx, 1u)))
+                                  : s.base_chunks;
+    const int least = staged_scene ? 1 : 4;  // samples a chunk takes per round, at least
+    const int cap = g_adaptive_chunks > 0 ? std::min(g_adaptive_chunks, room) : room;
     const int step = local_target(std::min(round, total)), start = local_target(std::min(first, total));
-    while (2 * chunks <= cap && step % (2 * chunks) == 0 && start % (2 * chunks) == 0 && step / (2 * chunks) >= 4) chunks *= 2;
+    while (2 * chunks <= cap && step % (2 * chunks) == 0 && start % (2 * chunks) == 0 && step / (2 * chunks) >= least) chunks *= 2;
+    while (chunks > 1 && fit_chunks(s, chunks) < chunks) chunks /= 2;  // less memory than that: fewer chunks
   }
+  RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict, false);  // after the arrays may have grown
   p.chunks = chunks;
   p.chunk_spp = (spp + chunks - 1) / chunks;
   p.acc2 = s.acc2;

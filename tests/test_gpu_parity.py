@@ -1483,6 +1483,42 @@ def test_large_scene_at_its_own_size(gpu):
         L.pt_set_defer_shadow(1)
 
 
+def test_adaptive_render_of_a_scene_that_runs_staged(gpu):
+    """Adaptive sampling on a scene beyond the fused kernel's size (160 000 triangles, 13.6 MiB of tree): the render
+    takes 32 slots per pixel (one sample per slot in a round of 32) whatever was rendered before it, gives the same
+    bits from the staged and the fused kernels and when repeated after other renders, adapts, and stays close to the
+    fixed-count render of the same scene."""
+    L = gpu.lib()
+    w, h, spp, thr, mn = 320, 180, 256, 0.2, 32
+    try:
+        L.pt_scene_synthetic(42, 500, 2)
+        assert gpu.scene_info()["bvh_bytes"] > 8 << 20
+        L.pt_set_defer_shadow(0)
+        imgs, cnts = [], []
+        for pipeline in (0, 1, -1):
+            L.pt_set_pipeline(pipeline)
+            L.pt_set_frame(5)
+            imgs.append(gpu.render_rgb(w, h, spp, noise_threshold=thr, min_adaptive_samples=mn))
+            assert L.pt_last_render_chunks() == 32
+            cnts.append(gpu.sample_counts(w, h)[0])
+            if pipeline == 0:  # something else in between: a long fixed-count render that grows the state further
+                L.pt_set_frame(9)
+                fixed = gpu.render_rgb(w, h, spp)
+                assert L.pt_last_render_chunks() == 64
+        assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
+        assert np.array_equal(cnts[0], cnts[1]) and np.array_equal(cnts[0], cnts[2])
+        c = cnts[0]
+        assert c.min() >= mn and c.max() <= spp and (c % 32 == 0).all() and len(np.unique(c)) > 2
+        assert np.isfinite(imgs[0]).all()
+        assert abs(imgs[0].mean() - fixed.mean()) / fixed.mean() < 0.02
+        blocks = lambda a: a.reshape(h // 20, 20, w // 20, 20, 3).mean(axis=(1, 3))
+        assert np.abs(blocks(imgs[0]) - blocks(fixed)).max() / fixed.mean() < 0.15
+    finally:
+        L.pt_scene_cornell()
+        L.pt_set_pipeline(1)
+        L.pt_set_defer_shadow(1)
+
+
 def test_instanced_scene_traces_and_renders_like_its_flat_copy(gpu, oracle):
     """A scene made of instances (two-level tree, rays taken to object space, normals brought back through the inverse
     transpose, a material per instance) against the same scene written out as world-space triangles: the closest
