@@ -1519,6 +1519,44 @@ def test_adaptive_render_of_a_scene_that_runs_staged(gpu):
         L.pt_set_defer_shadow(1)
 
 
+def test_one_sample_chunks_are_independent_between_pixels(gpu):
+    """A scene that runs staged renders 64 spp as 64 chunks of one sample, each with a stream of its own.  The error of
+    such a render must be noise that averages out over neighbouring pixels: the variance of 20 x 20 block means is
+    1/400 of the per-pixel variance; and what a sample costs in rays does not depend on how the samples are cut into
+    chunks.  (Streams that start from poorly mixed seeds give every pixel of the image the same first random number per
+    sample: the second check fails by 2 % with chunk_seed's finaliser taken out, the first one does not notice.)"""
+    L = gpu.lib()
+    w, h, spp = 320, 180, 64
+    try:
+        L.pt_scene_synthetic(42, 500, 2)
+        imgs = []
+        for frame in (1, 2, 3):
+            L.pt_set_frame(frame)
+            imgs.append(gpu.render_rgb(w, h, spp).astype(np.float64))
+            assert L.pt_last_render_chunks() == 64
+        ratios = []
+        for a, b in ((0, 1), (1, 2), (0, 2)):
+            d = np.clip(imgs[a] - imgs[b], -1.0, 1.0)  # fireflies out of the second moments
+            v_pix = (d ** 2).mean()
+            blk = d.reshape(h // 20, 20, w // 20, 20, 3).mean(axis=(1, 3))
+            ratios.append((blk ** 2).mean() * 400 / v_pix)
+        assert all(0.6 < r < 1.6 for r in ratios), ratios
+        # ... and the rays a sample takes on average do not depend on how the samples are cut into chunks: 16 chunks of
+        # one sample against 64 chunks of 16 (0.07 % of noise at this size; 2 % apart with the shared first draws).
+        # Sample ranges that start after sample 0: the stream that starts there is the reference's, whose first draw
+        # is the same all over the frame (1 % on the average of 16 samples).
+        import torch
+        sums = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda:0")
+        per_sample = []
+        for begin, n in ((1024, 16), (2048, 1024)):
+            L.pt_reset_ray_counts()
+            gpu.render_accumulate_device(sums, w, h, begin, n, 32, 4)
+            per_sample.append(sum(gpu.ray_counts()) / (w * h * n))
+        assert abs(per_sample[0] / per_sample[1] - 1.0) < 4e-3, per_sample
+    finally:
+        L.pt_scene_cornell()
+
+
 def test_instanced_scene_traces_and_renders_like_its_flat_copy(gpu, oracle):
     """A scene made of instances (two-level tree, rays taken to object space, normals brought back through the inverse
     transpose, a material per instance) against the same scene written out as world-space triangles: the closest
