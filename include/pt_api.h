@@ -269,6 +269,11 @@ PT_EXPORT double pt_last_render_ms(void);
  * in flight: min(64, 150994944 / (w*h)) chunks of as little as one sample, path state of 160 bytes per slot
  * growing on demand up to a quarter of the free device memory.  strict_parity: 1. */
 PT_EXPORT int pt_last_render_chunks(void);
+/* The rule itself, without a GPU (tests): chunks a fixed-count converge-mode render of w x h pixels and sample_count
+ * samples would take on a scene that runs staged by default (staged_scene != 0) or fused, in a renderer that holds
+ * have_chunks slots per pixel while free_bytes of device memory are free.  -1 for arguments out of range. */
+PT_EXPORT int pt_dbg_chunk_plan(int w, int h, int sample_count, int staged_scene, int have_chunks,
+                                unsigned long long free_bytes);
 
 /* Scene.  The built-in scene is the reference's Cornell box (optix_wrapper.cpp:379-489).
  * pt_scene_synthetic replaces it by the box plus a seeded grid of triangulated spheres

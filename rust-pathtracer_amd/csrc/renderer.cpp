@@ -303,6 +303,14 @@ void alloc_slots(State& s, int chunks) {
   }
 }
 
+// How many of `want` slots per pixel a renderer that holds `have` may grow to: what a quarter of the memory that
+// is free (its own arrays counted as free) has room for, and never fewer than it holds.
+int chunks_that_fit(size_t px, int want, int have, size_t free_bytes) {
+  const size_t own = px * (size_t)have * kSlotBytes;
+  while (want > have && px * (size_t)want * kSlotBytes > (free_bytes + own) / 4) --want;
+  return want;
+}
+
 // The state arrays hold `chunks` slots per pixel after this, or as many as a quarter of the free memory allows.
 int fit_chunks(State& s, int chunks) {
   if (s.borrowed) return std::min(chunks, s.max_chunks);
@@ -311,8 +319,7 @@ int fit_chunks(State& s, int chunks) {
     size_t free_b = 0, total_b = 0;
     HIP_CHECK(hipSetDevice(s.device));
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    const size_t have = px * (size_t)s.max_chunks * kSlotBytes;
-    while (chunks > s.max_chunks && px * (size_t)chunks * kSlotBytes > (free_b + have) / 4) --chunks;
+    chunks = chunks_that_fit(px, chunks, s.max_chunks, free_b);
     if (chunks > s.max_chunks) {
       HIP_CHECK(hipStreamSynchronize(s.stream));
       alloc_slots(s, chunks);
@@ -331,20 +338,23 @@ bool staged_by_default(const State& s) { return s.scene.inst_records != nullptr 
 // their samples are in flight at once -- every launch is one bounce of every live path, so fewer, larger launches
 // leave fewer half-empty waves behind: up to 64 chunks of as little as one sample, 144 M slots (22 GB of the
 // GPU's 288) at most and never more than a quarter of what is free.  The state arrays grow when a render needs it.
-int chunks_for_render(State& s, int sample_count, bool strict) {
-  if (strict) return 1;
+int planned_chunks(size_t px, int sample_count, bool staged_scene) {
   static const int chunk_override = getenv("PT_CHUNKS") ? atoi(getenv("PT_CHUNKS")) : 0;
   static const size_t target_env = getenv("PT_TARGET_SLOTS") ? (size_t)atoll(getenv("PT_TARGET_SLOTS")) : 0;
   static const int min_chunk_env = getenv("PT_MIN_CHUNK_SAMPLES") ? std::max(atoi(getenv("PT_MIN_CHUNK_SAMPLES")), 1) : 0;
-  const size_t px = std::max<size_t>((size_t)s.width * (size_t)s.height, 1);
-  const bool staged_scene = !s.borrowed && staged_by_default(s);
+  px = std::max<size_t>(px, 1);
   const int most = staged_scene ? 64 : 16;
   const size_t target = target_env ? target_env : (staged_scene ? (size_t)144 << 20 : kTargetSlots);
   const int min_chunk = min_chunk_env ? min_chunk_env : (staged_scene ? 1 : 32);
   int chunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)most, target / px));
   if (chunk_override > 0) chunks = std::min(chunk_override, most);
   while (chunks > 1 && sample_count / chunks < min_chunk) --chunks;
-  return fit_chunks(s, chunks);
+  return chunks;
+}
+int chunks_for_render(State& s, int sample_count, bool strict) {
+  if (strict) return 1;
+  const size_t px = (size_t)s.width * (size_t)s.height;
+  return fit_chunks(s, planned_chunks(px, sample_count, !s.borrowed && staged_by_default(s)));
 }
 
 // optix_wrapper.cpp:784-920
@@ -1402,6 +1412,11 @@ int pt_dbg_profile_counters(uint64_t* out64) {
 }
 double pt_last_render_ms(void) { return g_handle ? g_handle->last_render_ms : 0.0; }
 int pt_last_render_chunks(void) { return g_handle ? g_handle->last_chunks : 0; }
+int pt_dbg_chunk_plan(int w, int h, int sample_count, int staged_scene, int have_chunks, unsigned long long free_bytes) {
+  if (w <= 0 || h <= 0 || sample_count < 0 || have_chunks < 1) return -1;
+  const size_t px = (size_t)w * (size_t)h;
+  return chunks_that_fit(px, planned_chunks(px, sample_count, staged_scene != 0), have_chunks, (size_t)free_bytes);
+}
 
 void pt_scene_cornell(void) {
   g_scene = make_cornell();
