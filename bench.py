@@ -67,6 +67,48 @@ def boundary_timings(ptamd, L, w, h, spp, max_depth):
     return out
 
 
+def large_scene_child():
+    """Runs in a process of its own (a failure here must not take the headline line with it): the stress
+    configuration -- the room with 2 500 spheres of 5 120 triangles, 12.8 M triangles, 1.1 GB of tree in HBM -- at
+    3840x2160, 16 samples per pixel, default pipeline (staged kernels, every sample in flight), sums left on the
+    device as in the headline.  Prints one JSON object."""
+    import ptamd
+    L = ptamd.lib()
+    L.pt_set_mode(ptamd.MODE_CONVERGE)
+    w, h, spp = 3840, 2160, 16
+    t = time.perf_counter()
+    L.pt_scene_synthetic(42, 2500, 4)
+    sums = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ptamd.render_accumulate_device(sums, w, h, 0, spp, 32, 1)  # builds and uploads the tree, grows the path state
+    first_s = time.perf_counter() - t
+    info = ptamd.scene_info()
+    ms = []
+    for frame in (2, 3):
+        L.pt_reset_ray_counts()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        ptamd.render_accumulate_device(sums, w, h, 0, spp, 32, frame)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t) * 1e3)
+    rays = sum(ptamd.ray_counts())
+    print(json.dumps({"workload": f"synthetic_{info['triangles']}_triangles_{w}x{h}_{spp}spp_depth32_converge",
+                      "value": rays / (ms[-1] * 1e-3) / 1e6, "unit": "Mrays/s", "ms": ms[-1], "rays": rays,
+                      "bvh_bytes": info["bvh_bytes"], "sample_chunks": L.pt_last_render_chunks(),
+                      "scene_build_upload_first_render_s": first_s}), flush=True)
+
+
+def large_scene_timing():
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--large-scene-child"], capture_output=True, text=True,
+                           timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or "no output")[-300:]}
+    except Exception as e:  # a timeout, a missing interpreter: reported, never fatal
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +122,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=48)
     ap.add_argument("--no-boundary", action="store_true", help="skip the optix_render_rgb / demosaic timings")
+    ap.add_argument("--no-large-scene", action="store_true", help="skip the 12.8 M-triangle configuration (a child process)")
+    ap.add_argument("--large-scene-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.large_scene_child:
+        large_scene_child()
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -214,6 +261,8 @@ def main():
             result["cpu_baseline"] = {"value": sum(crays) / ct / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
                                       "sample": f"same scene and camera, {w}x{h}, {args.cpu_spp} spp ({sum(crays)} rays, {ct:.1f} s); "
                                                 "rays/s does not depend on spp"}
+        if world == 1 and not args.no_large_scene:
+            result["large_scene"] = large_scene_timing()
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

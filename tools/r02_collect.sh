@@ -6,10 +6,10 @@ set -e
 OUT=gpurun_out/r02
 mkdir -p $OUT
 # 1. kernel trace + stats of the bench command (fused, 1080p 1024 spp, one step)
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_f -o pf -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary > $OUT/bench_profiled.json 2> $OUT/prof_f.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_f -o pf -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary --no-large-scene > $OUT/bench_profiled.json 2> $OUT/prof_f.err
 # 2. PMC passes of the same command
 run() { local name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_fused/$name -o $name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_fused/$name -o $name -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary --no-large-scene > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err; }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
 run sq2 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
 run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
