@@ -11,6 +11,7 @@ L.guiding_set_grid_res(4, 4, 4)
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     kind = int(rng.integers(0, 4))
     n, sub = int(rng.integers(1, 60)), int(rng.integers(0, 3))
+    if rng.integers(0, 4) == 0: n, sub = int(rng.integers(150, 400)), 2  # beyond 2 MiB of tree: staged by default, state grows
     if kind == 0: L.pt_scene_cornell()
     elif kind == 1: L.pt_scene_synthetic(int(rng.integers(1, 99)), n, sub)
     else: L.pt_scene_synthetic_instanced(int(rng.integers(1, 99)), n, sub)
