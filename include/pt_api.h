@@ -118,7 +118,7 @@ PT_EXPORT int  pt_get_mode(void);
  * separate kernels over SoA queues in HBM; PT_PIPELINE_FUSED keeps a path in registers
  * for several bounces per launch.  Same results, bit for bit.  Env: PT_PIPELINE=staged|fused.
  * PT_PIPELINE_AUTO (the default when neither the call nor the variable chooses): scenes whose BVH is
- * at most 2 MiB run fused; larger ones run staged until few paths are left, then finish fused. */
+ * at most 256 KiB run fused; larger ones run staged until few paths are left, then finish fused. */
 enum { PT_PIPELINE_AUTO = -1, PT_PIPELINE_STAGED = 0, PT_PIPELINE_FUSED = 1 };
 PT_EXPORT void pt_set_pipeline(int pipeline);
 PT_EXPORT int  pt_get_pipeline(void);
@@ -265,8 +265,8 @@ PT_EXPORT int pt_dbg_profile_counters(uint64_t* out64);
 PT_EXPORT double pt_last_render_ms(void);
 /* Chunks the last render split every pixel's sample range into (each chunk is a path slot with a random stream of
  * its own, all in flight together).  Fixed-count renders of scenes that run fused: min(16, 8388608 / (w*h)), lowered
- * until every chunk has 32 samples.  Scenes that run staged by default (trees beyond 2 MiB, instances) keep more
- * in flight: min(64, 150994944 / (w*h)) chunks of as little as one sample, path state of 160 bytes per slot
+ * until every chunk has 32 samples.  Scenes that run staged by default (trees beyond 256 KiB, instances) keep more
+ * in flight: min(64, 150994944 / (w*h)) chunks of as little as one sample, path state of 164 bytes per slot
  * growing on demand up to a quarter of the free device memory.  strict_parity: 1. */
 PT_EXPORT int pt_last_render_chunks(void);
 /* The rule itself, without a GPU (tests): chunks a fixed-count converge-mode render of w x h pixels and sample_count

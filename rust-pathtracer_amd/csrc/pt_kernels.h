@@ -40,6 +40,8 @@ struct RenderParams {
   int* started;  // samples started per pixel
   // queues
   uint32_t* queue[2];
+  uint32_t* queue_tmp;     // staged pipeline: survivors of a generate pass, compacted per tile of 1024 entries
+  uint32_t* tiles;         // ... their counts per tile, then the tiles' places in the next queue
   uint32_t* counters;      // CNT_WORDS words
   unsigned long long* ray_counters;  // [0] radiance rays, [1] shadow rays
   q4* hits;                // per queue slot: prim bits, t, b1, b2

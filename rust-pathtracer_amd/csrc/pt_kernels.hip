@@ -218,21 +218,62 @@ void launch_bin_train(const TrainRec* ring, uint32_t capacity, const BinField& f
 }
 
 // ------------------------------------------------------------------------- generate
+// The queue the staged kernels work through is kept in slot order: path state is found by slot number, and a
+// wave whose 64 queue entries are 64 neighbouring slots reads and writes whole cache lines of it.  A compaction
+// that appends the survivors of its blocks in the order the blocks happen to arrive keeps that only for a while
+// (every pass cuts the runs of neighbours at its block borders: after a few hundred passes the queue is a
+// shuffle, and k_shade needs nearly twice as long per path).  So the pass is stable: every tile of 1024 entries
+// compacts its survivors in place into queue_tmp and records how many there are, a scan turns the counts into
+// places, and a third kernel moves the tiles there.
+constexpr uint32_t kTile = 1024;  // 4 waves x 4 rows of 64 consecutive entries
+
+// Ranks of a block's kept items in (wave, item, lane) order, which is entry order when a wave holds ITEMS rows of
+// 64 consecutive entries, lane by lane; returns how many are kept in all.
+template <int ITEMS>
+__device__ __forceinline__ uint32_t block_rank_slots(const bool (&keep)[ITEMS], uint32_t (&rank)[ITEMS]) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_total;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  uint32_t in_wave = 0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const unsigned long long mask = __ballot(keep[k]);
+    rank[k] = in_wave + (uint32_t)__popcll(mask & lower);
+    in_wave += (uint32_t)__popcll(mask);
+  }
+  if (lane == 0) s_wave[wave] = in_wave;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+    s_total = total;
+  }
+  __syncthreads();
+  const uint32_t base = s_wave[wave];
+  const uint32_t total = s_total;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) rank[k] += base;
+  __syncthreads();  // s_wave / s_total are reused by the next call
+  return total;
+}
+
 __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
   constexpr int ITEMS = 4;
   const uint32_t n = p.counters[qin];
+  const uint32_t n_tiles = (n + kTile - 1u) / kTile;
   const uint32_t* q_in = p.queue[qin];
-  uint32_t* q_out = p.queue[qin ^ 1];
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // the traversal kernels that follow start at the front of their queues
     p.counters[CNT_EXTEND] = 0u;
     p.counters[CNT_OCCLUDE] = 0u;
   }
-  for (uint32_t base = blockIdx.x * (blockDim.x * ITEMS); base < n; base += gridDim.x * (blockDim.x * ITEMS)) {
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t base = tile * kTile;
     bool keep[ITEMS];
     uint32_t pixel[ITEMS];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
-      const uint32_t i = base + (uint32_t)k * blockDim.x + threadIdx.x;
+      const uint32_t i = base + (threadIdx.x >> 6) * (64u * ITEMS) + (uint32_t)k * 64u + (threadIdx.x & 63u);
       keep[k] = false;
       pixel[k] = 0;
       if (i >= n) continue;
@@ -262,11 +303,61 @@ __global__ void __launch_bounds__(256) k_generate(RenderParams p, int qin) {
         p.started[pixel[k]] = local + 1;
       }
     }
-    uint32_t slot[ITEMS];
-    block_append_slots<ITEMS>(keep, &p.counters[qin ^ 1], slot);
+    uint32_t rank[ITEMS];
+    const uint32_t total = block_rank_slots<ITEMS>(keep, rank);
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k)
-      if (keep[k]) q_out[slot[k]] = pixel[k];
+      if (keep[k]) p.queue_tmp[base + rank[k]] = pixel[k];
+    if (threadIdx.x == 0) p.tiles[tile] = total;
+  }
+}
+// counts per tile -> the tiles' places in the next queue (tiles[n_tiles] = its length, also put in its counter)
+__global__ void __launch_bounds__(1024) k_tile_scan(RenderParams p, int qin) {
+  constexpr uint32_t PER = 16;  // consecutive tiles per thread
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  const uint32_t n_tiles = (p.counters[qin] + kTile - 1u) / kTile;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0u;
+  __syncthreads();
+  for (uint32_t start = 0; start < n_tiles; start += blockDim.x * PER) {
+    const uint32_t first = start + threadIdx.x * PER;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      v[k] = first + k < n_tiles ? p.tiles[first + k] : 0u;
+      sum += v[k];
+    }
+    uint32_t incl = sum;  // inclusive scan of the threads' sums over the wave ...
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off);
+      if ((int)lane >= off) incl += up;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = s_carry;  // ... and over the waves in front
+    for (uint32_t w = 0; w < wave; ++w) before += s_wave[w];
+    uint32_t at = before + incl - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      if (first + k < n_tiles) p.tiles[first + k] = at;
+      at += v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1u) s_carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    p.tiles[n_tiles] = s_carry;
+    p.counters[qin ^ 1] = s_carry;
+  }
+}
+__global__ void __launch_bounds__(256) k_tile_gather(RenderParams p, int qin) {
+  const uint32_t n_tiles = (p.counters[qin] + kTile - 1u) / kTile;
+  uint32_t* q_out = p.queue[qin ^ 1];
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t at = p.tiles[tile], count = p.tiles[tile + 1u] - at;
+    for (uint32_t t = threadIdx.x; t < count; t += blockDim.x) q_out[at + t] = p.queue_tmp[tile * kTile + t];
   }
 }
 
@@ -961,6 +1052,8 @@ static inline size_t stack_bytes(const RenderParams& p, const LaunchCfg& c) {
 
 void launch_generate(const RenderParams& p, int qin, const LaunchCfg& c) {
   k_generate<<<c.blocks, c.threads, 0, c.stream>>>(p, qin);
+  k_tile_scan<<<1, 1024, 0, c.stream>>>(p, qin);
+  k_tile_gather<<<c.blocks, c.threads, 0, c.stream>>>(p, qin);
   PT_KCHECK();
 }
 void launch_extend(const RenderParams& p, int q, const LaunchCfg& c) {

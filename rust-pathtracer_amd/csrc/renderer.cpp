@@ -283,11 +283,11 @@ int max_chunks_for(size_t px) {
 }
 
 // The per-slot arrays for `chunks` slots per pixel (whatever they held is gone).
-constexpr size_t kSlotBytes = 9 * 16 + 4 * 4;  // nine 16-byte words, started, hit_inst and two queue entries
+constexpr size_t kSlotBytes = 9 * 16 + 5 * 4;  // nine 16-byte words, started, hit_inst and three queue entries
 void alloc_slots(State& s, int chunks) {
   dev_free(s.st_o); dev_free(s.st_d); dev_free(s.st_s); dev_free(s.st_m); dev_free(s.acc); dev_free(s.hits);
   dev_free(s.sh_o); dev_free(s.sh_d); dev_free(s.sh_c); dev_free(s.started); dev_free(s.hit_inst);
-  dev_free(s.queue[0]); dev_free(s.queue[1]);
+  dev_free(s.queue[0]); dev_free(s.queue[1]); dev_free(s.queue_tmp); dev_free(s.tiles);
   s.max_chunks = chunks;
   const size_t slots = (size_t)s.width * (size_t)s.height * (size_t)chunks;
   s.st_o = dev_alloc<q4>(slots); s.st_d = dev_alloc<q4>(slots); s.st_s = dev_alloc<q4>(slots);
@@ -297,6 +297,8 @@ void alloc_slots(State& s, int chunks) {
   s.hit_inst = dev_alloc<uint32_t>(slots);
   s.queue[0] = dev_alloc<uint32_t>(slots);
   s.queue[1] = dev_alloc<uint32_t>(slots);
+  s.queue_tmp = dev_alloc<uint32_t>(slots);
+  s.tiles = dev_alloc<uint32_t>(slots / 1024 + 2);
   if (s.acc2) {  // the adaptive renders' sum of squares is per slot too
     dev_free(s.acc2);
     s.acc2 = dev_alloc<q4>(slots);
@@ -329,8 +331,8 @@ int fit_chunks(State& s, int chunks) {
 }
 
 // Trees up to this size run fused by default, larger ones staged (measured on spheres in the room at 1080p, 256
-// samples: 1.4 MiB fused 4.9 against staged 4.5 Grays/s, 2.7 MiB 3.5 against 4.0).
-constexpr size_t kFusedTreeBytes = (size_t)2u << 20;
+// samples: 0.14 MiB of tree fused 9.9 against staged 7.7 Grays/s, 0.55 MiB 5.5 against 6.2, 1.4 MiB 5.0 against 5.8).
+constexpr size_t kFusedTreeBytes = (size_t)256u << 10;
 bool staged_by_default(const State& s) { return s.scene.inst_records != nullptr || s.bvh_bytes > kFusedTreeBytes; }
 
 // Chunks (slots per pixel) of a fixed-count render.  Scenes that run fused keep about 8 M slots in flight in
@@ -489,6 +491,8 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   p.st_o = s.st_o; p.st_d = s.st_d; p.st_s = s.st_s; p.st_m = s.st_m; p.acc = s.acc;
   p.started = s.started;
   p.queue[0] = s.queue[0]; p.queue[1] = s.queue[1];
+  p.queue_tmp = s.queue_tmp;
+  p.tiles = s.tiles;
   p.counters = s.counters;
   p.ray_counters = s.ray_counters;
   p.hits = s.hits;
@@ -955,7 +959,7 @@ State::~State() {
   dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade); dev_free(d_wide); dev_free(d_home_wide);
   dev_free(st_o); dev_free(st_d); dev_free(st_s); dev_free(st_m); dev_free(acc); dev_free(hits);
   dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started); dev_free(hit_inst); dev_free(d_inst);
-  dev_free(queue[0]); dev_free(queue[1]); dev_free(counters); dev_free(ray_counters);
+  dev_free(queue[0]); dev_free(queue[1]); dev_free(queue_tmp); dev_free(tiles); dev_free(counters); dev_free(ray_counters);
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);
   dev_free(shared_acc); dev_free(shared_acc2); dev_free(shared_n);

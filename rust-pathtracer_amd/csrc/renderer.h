@@ -64,6 +64,8 @@ struct State {
   q4 *sh_o = nullptr, *sh_d = nullptr, *sh_c = nullptr;
   u4* st_m = nullptr;
   int* started = nullptr;
+  uint32_t* queue_tmp = nullptr;  // staged pipeline: scratch of the stable queue compaction
+  uint32_t* tiles = nullptr;
   uint32_t* queue[2] = {nullptr, nullptr};
   uint32_t* counters = nullptr;
   unsigned long long* ray_counters = nullptr;

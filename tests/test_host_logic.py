@@ -601,7 +601,7 @@ def test_later_sample_ranges_start_streams_that_differ_between_pixels(hostcheck)
 def test_chunk_plan(pt):
     """Slots per pixel of a fixed-count render.  Scenes that run fused: 8 Mi slots, chunks of 32 samples and more, 16
     at most.  Scenes that run staged: 144 Mi slots, chunks of one sample and more, 64 at most.  The renderer grows
-    to that if a quarter of the free memory (its own 160 bytes per slot counted as free) holds it, else to what
+    to that if a quarter of the free memory (its own 164 bytes per slot counted as free) holds it, else to what
     does, and never shrinks."""
     plan = pt.lib().pt_dbg_chunk_plan
     big = 1 << 40
@@ -617,10 +617,10 @@ def test_chunk_plan(pt):
     assert plan(3840, 2160, 4096, 1, 1, big) == 18      # 144 Mi / 8.3 M pixels
     assert plan(3840, 2160, 2, 1, 1, big) == 2 and plan(3840, 2160, 1, 1, 1, big) == 1
     assert plan(320, 180, 5, 1, 1, big) == 5
-    # memory: 1080p, 64 chunks are 21.2 GB
-    need = 1920 * 1080 * 64 * 160
+    # memory: 1080p, 64 chunks are 21.8 GB
+    need = 1920 * 1080 * 64 * 164
     assert plan(1920, 1080, 256, 1, 1, 4 * need) == 64
-    assert plan(1920, 1080, 256, 1, 1, 4 * need - 1920 * 1080 * 160 - 1) == 63  # its own chunk counts as free
+    assert plan(1920, 1080, 256, 1, 1, 4 * need - 1920 * 1080 * 164 - 1) == 63  # its own chunk counts as free
     assert plan(1920, 1080, 256, 1, 1, 2 * need) == 32
     assert plan(1920, 1080, 256, 1, 4, 0) == 4          # nothing free: what it holds
     assert plan(1920, 1080, 256, 1, 64, 0) == 64

@@ -10,7 +10,7 @@ if os.environ.get('INSTANCED'): L.pt_scene_synthetic_instanced(42, n, sub)  # ro
 else: L.pt_scene_synthetic(42, n, sub)
 ptamd.render_rgb(64, 36, 1)
 for spp in (int(a) for a in sys.argv[5:]):
-    for pipe in (0, -1):
+    for pipe in ([int(x) for x in os.environ['PIPES'].split(',')] if os.environ.get('PIPES') else (0, -1)):
         L.pt_set_pipeline(pipe)
         L.pt_reset_ray_counts(); L.pt_set_frame(0); L.pt_reset_kernel_stats(); L.pt_set_kernel_timing(1)
         img = ptamd.render_rgb(w, h, spp)
