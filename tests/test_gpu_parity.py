@@ -1611,7 +1611,7 @@ def test_instanced_scene_traces_and_renders_like_its_flat_copy(gpu, oracle):
 
 
 def test_full_size_1080p_properties(gpu):
-    """BASELINE's 1080p configuration at reduced spp: properties that do not need a CPU render."""
+    """The 1920x1080 headline configuration at reduced spp: properties that do not need a CPU render."""
     L = gpu.lib()
     L.pt_set_frame(0)
     L.pt_reset_ray_counts()
