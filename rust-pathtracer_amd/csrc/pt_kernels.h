@@ -49,6 +49,7 @@ struct RenderParams {
   q4* sh_o;                // shadow queue: origin.xyz, tmax
   q4* sh_d;                //               dir.xyz, pixel bits
   q4* sh_c;                //               contrib.xyz
+  uint32_t* sh_count;      // shadow rays of every 256 queue entries, stored at the front of those 256 records
   // guiding training ring (optix_device.cu:10-12)
   TrainRec* train;
   uint32_t* train_write_idx;

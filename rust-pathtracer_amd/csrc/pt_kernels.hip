@@ -492,16 +492,29 @@ __global__ void __launch_bounds__(256) k_shade(RenderParams p, int q) {
       store_state(p, pixel, ps);
     }
     if (TRAIN && valid) capture_train(p, tv, seed_after, pixel, captured);
-    // the shadow record sits at the path's own queue position (no compaction, no atomic):
-    // tmax < 0 marks "no shadow ray", which the occlusion kernel skips
-    if (valid) {
-      if (sr.valid) {
-        p.sh_o[i] = q4{sr.o.x, sr.o.y, sr.o.z, sr.tmax};
-        p.sh_d[i] = q4{sr.d.x, sr.d.y, sr.d.z, u2f(pixel)};
-        p.sh_c[i] = q4{sr.contrib.x, sr.contrib.y, sr.contrib.z, u2f(sr.origin)};
-      } else {
-        p.sh_o[i] = q4{0.f, 0.f, 0.f, -1.0f};
+    // About half of the paths make a shadow ray.  The records of a block's 256 paths go to the front of the block's
+    // 256 places, in path order, and their number into sh_count (no atomic): the occlusion kernel then takes
+    // shadow rays only, instead of finding out record by record that there is nothing to trace.
+    {
+      __shared__ uint32_t s_rays[4];
+      const bool has = valid && sr.valid;
+      const unsigned long long mask = __ballot(has);
+      const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+      if (lane == 0u) s_rays[wave] = (uint32_t)__popcll(mask);
+      __syncthreads();
+      uint32_t before = 0u, total = 0u;
+      for (uint32_t w = 0; w < 4u; ++w) {
+        if (w < wave) before += s_rays[w];
+        total += s_rays[w];
       }
+      if (has) {
+        const uint32_t j = base + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        p.sh_o[j] = q4{sr.o.x, sr.o.y, sr.o.z, sr.tmax};
+        p.sh_d[j] = q4{sr.d.x, sr.d.y, sr.d.z, u2f(pixel)};
+        p.sh_c[j] = q4{sr.contrib.x, sr.contrib.y, sr.contrib.z, u2f(sr.origin)};
+      }
+      if (threadIdx.x == 0u) p.sh_count[base >> 8] = total;
+      __syncthreads();  // s_rays is reused by the next pass
     }
   }
   if (TRAIN) flush_train_count(p, captured);
@@ -521,27 +534,33 @@ __global__ void __launch_bounds__(256) k_occlude(RenderParams p, int q) {
   f3 ro = mk3(0.f), rd = mk3(0.f);
   uint32_t idx = 0xffffffffu;
   prof_begin();
-  for (;;) {  // same scheme as k_extend; records without a shadow ray (tmax < 0) finish at once
+  for (;;) {  // same scheme as k_extend
     const unsigned long long idle = __ballot(idx == 0xffffffffu);
     const uint32_t n_idle = (uint32_t)__popcll(idle);
     const bool refill = n_idle >= (uint32_t)p.refill_lanes || n_idle == 64u;
     if (refill && r.more && r.cursor >= r.end) take_range(r, &p.counters[CNT_OCCLUDE], n);
     if (r.cursor < r.end && refill) {
-      if (idx == 0xffffffffu) {
-        const uint32_t i = r.cursor + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-        if (i < r.end) {
-          const q4 o = p.sh_o[i];
-          if (o.w >= 0.0f) {
+      // shadow records sit at the front of every 256 places (k_shade): sh_count says how many
+      const uint32_t have = p.sh_count[r.cursor >> 8], at = r.cursor & 255u;
+      if (at >= have) {
+        r.cursor = (r.cursor | 255u) + 1u;  // nothing left in these 256: on to the next
+      } else {
+        const uint32_t left = have - at < r.end - r.cursor ? have - at : r.end - r.cursor;
+        const uint32_t take = n_idle < left ? n_idle : left;
+        if (idx == 0xffffffffu) {
+          const uint32_t k = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+          if (k < take) {
+            const uint32_t i = r.cursor + k;
             idx = i;
-            const q4 d = p.sh_d[i];
+            const q4 o = p.sh_o[i], d = p.sh_d[i];
             traced++;
             ro = mk3(o.x, o.y, o.z);
             rd = mk3(d.x, d.y, d.z);
             ts.begin(p.scene, ro, rd, o.w, f2u(p.sh_c[i].w));
           }
         }
+        r.cursor += take;
       }
-      r.cursor += n_idle;
     } else if (n_idle == 64u) {
       break;
     }

@@ -286,13 +286,14 @@ int max_chunks_for(size_t px) {
 constexpr size_t kSlotBytes = 9 * 16 + 5 * 4;  // nine 16-byte words, started, hit_inst and three queue entries
 void alloc_slots(State& s, int chunks) {
   dev_free(s.st_o); dev_free(s.st_d); dev_free(s.st_s); dev_free(s.st_m); dev_free(s.acc); dev_free(s.hits);
-  dev_free(s.sh_o); dev_free(s.sh_d); dev_free(s.sh_c); dev_free(s.started); dev_free(s.hit_inst);
+  dev_free(s.sh_o); dev_free(s.sh_d); dev_free(s.sh_c); dev_free(s.sh_count); dev_free(s.started); dev_free(s.hit_inst);
   dev_free(s.queue[0]); dev_free(s.queue[1]); dev_free(s.queue_tmp); dev_free(s.tiles);
   s.max_chunks = chunks;
   const size_t slots = (size_t)s.width * (size_t)s.height * (size_t)chunks;
   s.st_o = dev_alloc<q4>(slots); s.st_d = dev_alloc<q4>(slots); s.st_s = dev_alloc<q4>(slots);
   s.st_m = dev_alloc<u4>(slots); s.acc = dev_alloc<q4>(slots); s.hits = dev_alloc<q4>(slots);
   s.sh_o = dev_alloc<q4>(slots); s.sh_d = dev_alloc<q4>(slots); s.sh_c = dev_alloc<q4>(slots);
+  s.sh_count = dev_alloc<uint32_t>(slots / 256 + 2);
   s.started = dev_alloc<int>(slots);
   s.hit_inst = dev_alloc<uint32_t>(slots);
   s.queue[0] = dev_alloc<uint32_t>(slots);
@@ -498,6 +499,7 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   p.hits = s.hits;
   p.hit_inst = s.hit_inst;
   p.sh_o = s.sh_o; p.sh_d = s.sh_d; p.sh_c = s.sh_c;
+  p.sh_count = s.sh_count;
   // optix_device.cu:432: training records are captured whenever the ring exists
   p.train = s.d_train;
   p.train_write_idx = s.d_train_idx;
@@ -958,7 +960,7 @@ State::~State() {
   for (TimedLaunch& t : timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
   dev_free(d_nodes); dev_free(d_tris); dev_free(d_shade); dev_free(d_wide); dev_free(d_home_wide);
   dev_free(st_o); dev_free(st_d); dev_free(st_s); dev_free(st_m); dev_free(acc); dev_free(hits);
-  dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(started); dev_free(hit_inst); dev_free(d_inst);
+  dev_free(sh_o); dev_free(sh_d); dev_free(sh_c); dev_free(sh_count); dev_free(started); dev_free(hit_inst); dev_free(d_inst);
   dev_free(queue[0]); dev_free(queue[1]); dev_free(queue_tmp); dev_free(tiles); dev_free(counters); dev_free(ray_counters);
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);

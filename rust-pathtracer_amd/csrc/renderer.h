@@ -62,6 +62,7 @@ struct State {
   uint32_t* hit_inst = nullptr;    // per queue slot: the instance of the hit (instanced scenes)
   q4* d_inst = nullptr;            // instanced scenes: 6 q4 per instance (SceneView::inst_records)
   q4 *sh_o = nullptr, *sh_d = nullptr, *sh_c = nullptr;
+  uint32_t* sh_count = nullptr;
   u4* st_m = nullptr;
   int* started = nullptr;
   uint32_t* queue_tmp = nullptr;  // staged pipeline: scratch of the stable queue compaction
