@@ -29,7 +29,7 @@ timeout -k 10 300 python3 tools/bigscene_stats.py 2500 4 3840 2160 16 > $OUT/big
 timeout -k 10 300 python3 tools/bigscene.py 40000 2 3840 2160 16 > $OUT/bigscene_40000.txt 2>&1
 # 5. PMC passes of the staged pipeline on the large scene
 runb() { local name=$1; shift
-  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_big/$name -o $name -- python3 tools/bigscene_stats.py 2500 4 3840 2160 4 > $OUT/pmcb_$name.log 2> $OUT/pmcb_$name.err; }
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_big/$name -o $name -- python3 tools/bigscene_stats.py 2500 4 3840 2160 16 > $OUT/pmcb_$name.log 2> $OUT/pmcb_$name.err; }
 runb sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
 runb sq2 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES
 runb tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum

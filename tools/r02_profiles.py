@@ -72,7 +72,7 @@ bench.py's HIP-event average for the fused kernel in the same run: {r['avg_launc
         + rd("bigscene_40000.txt")
         + (("\n# the room and one 320-triangle sphere placed 40 000 times (two-level tree, staged kernels; INSTANCED=1 tools/bigscene_spp.py 40000 2 3840 2160 16)\n"
             + rd("bigscene_instanced.txt")) if os.path.exists(f"{SRC}/bigscene_instanced.txt") else "")
-        + (("\n# section counters of the traversal kernels at 4 spp (profiling build; tools/sections_staged.py 2500 4 3840 2160 4)\n"
+        + (("\n# section counters of the traversal kernels at 16 spp (profiling build; tools/sections_staged.py 2500 4 3840 2160 16)\n"
             + rd("sections_staged.txt")) if os.path.exists(f"{SRC}/sections_staged.txt") else ""))
 
     # static issue cost of the fused kernel's instruction mix
