@@ -132,35 +132,6 @@ __device__ __forceinline__ void fold_squares(q4* acc2, uint32_t slot, f3 v) {
   acc2[slot] = a;
 }
 
-// Block-wide queue append for ITEMS candidates per thread: one returning atomic per block instead of
-// one per wave (the same-address atomics of a whole launch serialise in L2, ~4 ns each).
-// keep[k] tells whether the thread's k-th item survives; slot[k] receives its queue position.
-template <int ITEMS>
-__device__ __forceinline__ void block_append_slots(const bool (&keep)[ITEMS], uint32_t* counter, uint32_t (&slot)[ITEMS]) {
-  __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_base;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
-  uint32_t before = 0;  // survivors of this wave in earlier items
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) {
-    const unsigned long long mask = __ballot(keep[k]);
-    slot[k] = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    before += (uint32_t)__popcll(mask);
-  }
-  if (lane == 0) s_wave[wave] = before;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t total = 0;
-    for (uint32_t w = 0; w < nwaves; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
-    s_base = total ? atomicAdd(counter, total) : 0u;
-  }
-  __syncthreads();
-  const uint32_t base = s_base + s_wave[wave];
-#pragma unroll
-  for (int k = 0; k < ITEMS; ++k) slot[k] += base;
-  __syncthreads();  // s_wave / s_base are reused by the next call
-}
-
 __device__ __forceinline__ ShadeParams shade_params(const RenderParams& p) {
   return ShadeParams{p.frame, p.max_depth, p.guiding};
 }
