@@ -6,11 +6,15 @@
 
 One step = one full render pass of the hot path: every pixel of the 1080p frame takes 1024
 samples through the wavefront integrator (BVH traversal + shading + NEE), sums stay in HBM.
-With N ranks each GPU renders its own 1024-sample chunk of the same frame (weak scaling: the
-image gets N*1024 spp) and the per-pixel sums are all-reduced over RCCL at the end of the step.
+With N ranks the step is still ONE 1024-spp frame (--scaling strong, the default for N > 1): the
+samples are split by index over the ranks (sharded.split_samples: 128 per GPU at N = 8) and the
+per-pixel sums are all-reduced over RCCL at the end of the step.  --scaling weak gives every rank
+its own 1024 samples of the same frame instead (the image gets N*1024 spp); a strong run reports
+that figure too, as "weak_value", from a second timed loop after the first.
 A ray is one BVH query: every radiance ray plus every shadow ray actually traced.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -119,6 +123,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--max-depth", type=int, default=32)
     ap.add_argument("--pipeline", choices=["fused", "staged"], default="fused")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None,
+                    help="N > 1: split one frame's samples over the ranks (strong, default) or give every rank its own --spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=48)
     ap.add_argument("--no-boundary", action="store_true", help="skip the optix_render_rgb / demosaic timings")
@@ -157,48 +163,76 @@ def main():
     L.pt_set_pipeline(ptamd.PIPELINE_FUSED if args.pipeline == "fused" else ptamd.PIPELINE_STAGED)
     w, h, spp = args.width, args.height, args.spp
     sums = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
-    begin, count = sharded.chunk_of(rank, spp)
-
-    def step(frame):
-        sums.zero_()
-        torch.cuda.synchronize(dev)
-        ptamd.render_accumulate_device(sums, w, h, begin, count, args.max_depth, frame)
-        if world > 1:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(1 + i)
-    L.pt_reset_ray_counts()
-    L.pt_reset_kernel_stats()
-    L.pt_set_kernel_timing(1)  # HIP events on the render stream around every wavefront launch
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(101 + i)
-    sync()
-    elapsed = time.perf_counter() - t0
-    L.pt_set_kernel_timing(0)
+    def timed_run(begin, count, steps, first_frame):
+        """`steps` steps of this rank's samples [begin, begin + count), bracketed by barrier + synchronize on both
+        sides; returns (max-over-ranks seconds, radiance rays of all ranks, shadow rays of all ranks, this rank's rays)."""
+        def step(frame):
+            sums.zero_()
+            torch.cuda.synchronize(dev)
+            ptamd.render_accumulate_device(sums, w, h, begin, count, args.max_depth, frame)
+            if world > 1:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM)
 
-    rr, rs = ptamd.ray_counts()
-    stats = torch.tensor([elapsed, float(rr), float(rs)], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = stats[0:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tot = stats[1:3].clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed, rr_all, rs_all = float(tmax[0]), float(tot[0]), float(tot[1])
+        for i in range(args.warmup):
+            step(1 + i)
+        L.pt_reset_ray_counts()
+        L.pt_reset_kernel_stats()
+        L.pt_set_kernel_timing(1)  # HIP events on the render stream around every wavefront launch
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(first_frame + i)
+        sync()
+        elapsed = time.perf_counter() - t0
+        L.pt_set_kernel_timing(0)
+        rr, rs = ptamd.ray_counts()
+        if world > 1:
+            stats = torch.tensor([elapsed, float(rr), float(rs)], dtype=torch.float64, device=dev)
+            tmax = stats[0:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tot = stats[1:3].clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            return float(tmax[0]), float(tot[0]), float(tot[1]), (rr, rs)
+        return elapsed, float(rr), float(rs), (rr, rs)
+
+    if scaling == "strong":
+        begin, count = sharded.split_samples(spp, world)[rank]
+        total_spp = spp
     else:
-        rr_all, rs_all = float(rr), float(rs)
+        begin, count = sharded.chunk_of(rank, spp)
+        total_spp = spp * world
+    elapsed, rr_all, rs_all, (rr, rs) = timed_run(begin, count, args.steps, 101)
     rays_all = rr_all + rs_all
+    kid = ptamd.K_BOUNCE if args.pipeline == "fused" else ptamd.K_EXTEND
+    kst = ptamd.kernel_stats(kid)  # of the headline loop, before anything else is launched
+
+    extra = {}
+    if world > 1:
+        # the collective alone: the step's one all-reduce of the per-pixel sums, timed by itself
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(dev)
+        ar = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        extra["allreduce_ms"] = float(ar[0])
+        extra["allreduce_bytes"] = sums.numel() * 4
+        if scaling == "strong":  # the weak figure beside it: every rank its own `spp` samples
+            wb, wc = sharded.chunk_of(rank, spp)
+            w_el, w_rr, w_rs, _ = timed_run(wb, wc, max(1, min(args.steps, 3)), 201)
+            extra["weak_value"] = (w_rr + w_rs) / w_el / 1e6
+            extra["weak_ms_per_step"] = w_el / max(1, min(args.steps, 3)) * 1e3
+            extra["weak_total_spp"] = spp * world
 
     if rank == 0:
-        kid = ptamd.K_BOUNCE if args.pipeline == "fused" else ptamd.K_EXTEND
-        kst = ptamd.kernel_stats(kid)
         avg_ms = kst["total_ms"] / max(kst["timed"], 1)
         # dominant kernel: rays this rank traced per launch of it (the staged extend kernel only traces radiance rays)
         rays_per_launch = ((rr + rs) if args.pipeline == "fused" else rr) / max(kst["launches"], 1)
@@ -206,21 +240,31 @@ def main():
         achieved_tflops = FLOP_PER_RAY * rays_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # HBM bytes per launch and the VALU counters come from the committed PMC passes of this same command
         # (profiles/pmc_traffic.json, written by tools/r02_profiles.py): counters cannot be read inside the timed run
-        traffic, pmc = None, {}
+        traffic, pmc, counters_from = None, {}, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and (w, h, spp) == (1920, 1080, 1024):
+        if os.path.exists(tpath) and (w, h, count) == (1920, 1080, 1024):
             try:
-                pmc = json.load(open(tpath)).get(args.pipeline, {})
+                blob = open(tpath, "rb").read()
+                pmc = json.loads(blob).get(args.pipeline, {})
                 traffic = pmc.get("hbm_bytes_per_launch")
+                # provenance: these figures are replayed from the tracked file, not measured in this run
+                # (its git blob id, so that a reader can tell which collection they belong to)
+                counters_from = "profiles/pmc_traffic.json@" + hashlib.sha1(b"blob %d\0" % len(blob) + blob).hexdigest()[:12]
             except Exception:
-                traffic, pmc = None, {}
+                traffic, pmc, counters_from = None, {}, None
         common = {"kernel": ptamd.KERNEL_NAMES[kid], "avg_launch_ms": avg_ms, "launches": kst["launches"],
-                  "rays_per_launch": rays_per_launch, "traffic": traffic}
+                  "rays_per_launch": rays_per_launch, "traffic": traffic,
+                  "measured_here": ["avg_launch_ms", "launches", "rays_per_launch", "achieved", "frac"],
+                  "counters_from": counters_from, "counters_collected": pmc.get("collected")}
         hbm = dict(common, bound="hbm", achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                    frac=achieved_gbs / HBM_PEAK_GBS, bytes_per_ray=BYTES_PER_RAY)
         cyc = pmc.get("simd_cycles_per_valu_inst")
         valu = dict(common, bound="valu", achieved=achieved_tflops, peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved_tflops / VALU_PEAK_TFLOPS, flop_per_ray=FLOP_PER_RAY,
+                    flop_per_ray_basis="static count on the source (10 box tests x 20 + 6 item tests x 35 per BVH query, "
+                                       "350 per opaque shading step, transcendentals as 1), not a counter",
+                    lane_insts_per_ray_counted=(pmc["valu_insts_per_ray"] * 64.0 * pmc["valu_lane_utilisation"])
+                    if pmc.get("valu_insts_per_ray") and pmc.get("valu_lane_utilisation") else None,
                     # SIMD cycles that pass per vector instruction issued, against what this kernel's instruction
                     # mix costs to issue (tools/isa_cost.py on the kernel's ISA with the per-opcode costs measured by
                     # tools/valu_ops.hip: 2.4 / 4.2 / 8.2 cycles); lane_util = active lanes per vector instruction / 64
@@ -237,28 +281,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (built-in Cornell scene of the reference, generated in-process)",
             "config": {"workload": f"cornell_{w}x{h}_{spp}spp_depth{args.max_depth}_converge", "pipeline": args.pipeline,
-                       "spp_per_gpu": spp, "total_spp": spp * world, "parallelism": f"sample-sharded x{world}"},
-            "spp_per_s": spp * world * args.steps / elapsed,
-            "paths_per_s": float(w) * h * spp * world * args.steps / elapsed,
-            "rays_per_path": rays_all / (float(w) * h * spp * world * args.steps),
+                       "spp_per_gpu": count, "total_spp": total_spp, "parallelism": f"sample-sharded x{world}"},
+            "spp_per_s": total_spp * args.steps / elapsed,
+            "paths_per_s": float(w) * h * total_spp * args.steps / elapsed,
+            "rays_per_path": rays_all / (float(w) * h * total_spp * args.steps),
             # the fused kernel is bound by vector-instruction issue, the staged kernels by HBM
             "roofline": valu if fused else hbm,
             ("roofline_hbm_equiv" if fused else "roofline_valu"): hbm if fused else valu,
         }
+        result.update(extra)
         if world == 1 and not args.no_boundary:
             result.update(boundary_timings(ptamd, L, w, h, spp, args.max_depth))
         if world == 1 and not args.no_cpu_baseline:
             import orc
-            cores = min(os.cpu_count() or 1, 16)
+            # threads: the CPUs this job may use.  A one-GPU box of the pool grants 16 of the machine's CPUs and says so
+            # in OMP_NUM_THREADS (os.cpu_count() there is the whole machine); elsewhere, every CPU the process may run on
+            host_cores = os.cpu_count() or 1
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
+            granted = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+            cores = max(1, min(usable, granted if granted > 0 else usable, 256))
             t = time.perf_counter()
             _, _, _, crays = orc.render(w, h, args.cpu_spp, max_depth=args.max_depth, frame=101, mode=orc.CONVERGE, nthreads=cores)
             ct = time.perf_counter() - t
-            result["cpu_baseline"] = {"value": sum(crays) / ct / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            result["cpu_baseline"] = {"value": sum(crays) / ct / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores": host_cores,
+                                      "cores_rule": "min(CPUs in the affinity mask, OMP_NUM_THREADS if set: the box's CPU grant)",
+                                      "kind": "port",
                                       "sample": f"same scene and camera, {w}x{h}, {args.cpu_spp} spp ({sum(crays)} rays, {ct:.1f} s); "
                                                 "rays/s does not depend on spp"}
         if world == 1 and not args.no_large_scene:

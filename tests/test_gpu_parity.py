@@ -815,7 +815,7 @@ def test_strict_render_matches_golden(gpu, pipeline):
     L.pt_reset_ray_counts()
     img = gpu.render_rgb(32, 32, 4)
     close = (np.abs(img - g["rgb"]) <= 2e-3 + 2e-3 * np.abs(g["rgb"])).all(axis=2).mean()
-    assert close > 0.9, close
+    assert close > 0.93, close  # measured 0.947; the rest are the rays that start on a plane (next test)
     rr, rs = gpu.ray_counts()
     assert abs(rr - g["rays"][0]) / g["rays"][0] < 0.02 and abs(rs - g["rays"][1]) / g["rays"][1] < 0.02
     # replay semantics: 16 spp strict = 4 repeats of the same launch
@@ -900,7 +900,7 @@ def test_converged_image_parity(gpu, pipeline):
         errs[spp] = rel_rmse(img, ref)
         if spp == 1024:
             final = img
-    assert errs[1024] < 0.12, errs
+    assert errs[1024] < 0.065, errs  # measured 0.047 (the 4096-spp reference image's own noise is 0.029)
     assert 2.0 < errs[64] / errs[1024] < 6.0, errs  # ideal 4
     # unbiased mean per channel: sigma of the image-mean estimator from two independent frames
     L.pt_set_frame(20)
@@ -908,7 +908,7 @@ def test_converged_image_parity(gpu, pipeline):
     for c in range(3):
         sigma = abs(final[..., c].mean() - other[..., c].mean()) / np.sqrt(2) + 1e-4 * ref[..., c].mean() + \
             np.std(final[..., c] - other[..., c]) / np.sqrt(2 * final[..., c].size)
-        assert abs(final[..., c].mean() - ref[..., c].mean()) < 3 * sigma + 0.004 * ref[..., c].mean()
+        assert abs(final[..., c].mean() - ref[..., c].mean()) < 3 * sigma + 0.0015 * ref[..., c].mean()
 
 
 def test_short_paths_match_the_oracle(gpu, oracle):
@@ -931,8 +931,8 @@ def test_bayer_converged_parity(gpu):
     L.pt_set_frame(1)  # -> frame 2, the frame of the reference's Bayer call (src/main.rs:512-526)
     raw = gpu.render_bayer(64, 64, 1024, pattern=0)
     assert raw.min() >= 0
-    assert rel_rmse(raw, g["bayer"]) < 0.12
-    assert abs(raw.mean() - g["bayer"].mean()) / g["bayer"].mean() < 0.01
+    assert rel_rmse(raw, g["bayer"]) < 0.085  # measured 0.063
+    assert abs(raw.mean() - g["bayer"].mean()) / g["bayer"].mean() < 0.004  # measured 0.0006
 
 
 def test_sample_chunks_sum_like_ranks(gpu):
@@ -1384,6 +1384,85 @@ def test_demosaic_full_size_properties(gpu, oracle):
     assert np.allclose(flat[3:-3, 3:-3], 0.5, atol=1e-5)
 
 
+def test_bayer_render_and_demosaic_chain_at_full_size(gpu):
+    """The Bayer configuration as the host runs it (src/main.rs:512-555), at its own size: optix_render_bayer_f32 at
+    3840 x 2160, pattern 0, then the gradient demosaic of that mosaic on the device.  No CPU render of this size
+    exists, so the chain is checked through what must hold at any size: the mosaic is, bit for bit, the CFA channel
+    of the RGB render of the same frame; the side bars (open front) are zero in the mosaic and stay zero through the
+    demosaic; green sites keep their raw value; and the 40 x 40 block means of mosaic and demosaic agree with the
+    oracle's converged 96 x 54 image of the same view (same aspect, so a block is a pixel of it)."""
+    import torch
+    L = gpu.lib()
+    w, h, spp = 3840, 2160, 16
+    L.pt_set_frame(1)  # -> frame 2, the frame of the reference's Bayer call
+    raw = gpu.render_bayer(w, h, spp, pattern=0)
+    L.pt_set_frame(1)
+    rgb = gpu.render_rgb(w, h, spp)
+    assert raw.shape == (h, w) and np.isfinite(raw).all() and raw.min() >= 0
+    ys, xs = np.mgrid[0:h, 0:w]
+    ch = (xs & 1) + (ys & 1)  # RGGB: 0 / 1 / 1 / 2
+    assert np.array_equal(raw, np.maximum(np.take_along_axis(rgb, ch[..., None], 2)[..., 0], 0))
+    assert raw[:, :500].max() == 0 and raw[:, -500:].max() == 0
+    # demosaic on the device (pt_demosaic_device), as a host that keeps the mosaic resident would call it
+    d_raw = torch.from_numpy(raw).to("cuda:0").contiguous()
+    d_out = torch.empty(h * w * 3, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    assert L.pt_demosaic_device(d_raw.data_ptr(), w, h, 0, 0, d_out.data_ptr()) == 0
+    torch.cuda.synchronize()
+    dem = d_out.cpu().numpy().reshape(h, w, 3)
+    assert np.array_equal(dem, gpu.demosaic(raw, 0, 0))  # the host-buffer entry point runs the same kernel
+    assert np.isfinite(dem).all() and dem.min() >= 0
+    assert np.array_equal(dem[0::2, 1::2, 1], raw[0::2, 1::2]) and np.array_equal(dem[1::2, 0::2, 1], raw[1::2, 0::2])
+    assert dem[:, :496].max() == 0 and dem[:, -496:].max() == 0
+    # against the oracle's converged image: a 40 x 40 block of the 4K frame is one pixel of the 96 x 54 golden
+    ref = np.load(os.path.join(GOLD, "converge_96x54_spp4096_frame1.npz"))["rgb"]
+    blocks = lambda a: a.reshape(54, 40, 96, 40, -1).mean(axis=(1, 3))
+    dem_b, rgb_b = blocks(dem), blocks(rgb)
+    lit = ref.sum(axis=2) > 0.05
+    for img_b, tol_med, tol_rmse in ((rgb_b, 0.02, 0.06), (dem_b, 0.02, 0.07)):
+        rel = np.abs(img_b - ref)[lit] / (ref[lit] + 0.01)
+        assert np.median(rel) < tol_med, np.median(rel)
+        assert rel_rmse(img_b, ref) < tol_rmse, rel_rmse(img_b, ref)
+    for c in range(3):
+        assert abs(dem[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.02
+        assert abs(rgb[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.01
+    # the mosaic's own channel planes (quarter resolution each) against the golden's channels
+    for (dy, dx, c) in ((0, 0, 0), (0, 1, 1), (1, 0, 1), (1, 1, 2)):
+        plane = raw[dy::2, dx::2].reshape(54, 20, 96, 20).mean(axis=(1, 3))
+        assert abs(plane.mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.01
+
+
+def test_rays_that_start_on_a_plane_keep_their_small_known_bias(gpu):
+    """A path that leaves the glass box through its bottom face restarts exactly on the floor plane (the reference's
+    1e-3 offset, optix_device.cu:469-475): whether it sees the floor is rounding noise in the oracle and decided by
+    the fast triangle test's own sign here, so such paths always pass through the floor where about half of the
+    oracle's bounce.  The size of that difference is pinned here so that it cannot grow unnoticed: the strict-mode
+    launch traces between 97.5 % and 100 % of the oracle's rays (radiance and shadow), and the converged image keeps
+    at least 99.9 % of the oracle's mean in every channel (measured 0.9994-0.9999 at 1024 spp; two independent
+    frames are averaged to keep noise out of the ratio)."""
+    L = gpu.lib()
+    g = np.load(os.path.join(GOLD, "strict_32x32_spp4_frame1.npz"))
+    for pipeline in (0, 1):
+        L.pt_set_pipeline(pipeline)
+        L.pt_set_mode(gpu.MODE_STRICT)
+        L.pt_set_frame(0)
+        L.pt_reset_ray_counts()
+        gpu.render_rgb(32, 32, 4)
+        rr, rs = gpu.ray_counts()
+        assert 0.975 <= rr / g["rays"][0] <= 1.0, (rr, g["rays"][0])
+        assert 0.975 <= rs / g["rays"][1] <= 1.0, (rs, g["rays"][1])
+    L.pt_set_mode(gpu.MODE_CONVERGE)
+    L.pt_set_pipeline(1)
+    ref = np.load(os.path.join(GOLD, "converge_96x54_spp4096_frame1.npz"))["rgb"].astype(np.float64)
+    acc = np.zeros_like(ref)
+    frames = (10, 20, 30, 40)
+    for f in frames:
+        L.pt_set_frame(f)
+        acc += gpu.render_rgb(96, 54, 1024)
+    ratio = (acc / len(frames)).mean(axis=(0, 1)) / ref.mean(axis=(0, 1))
+    assert (ratio >= 0.999).all() and (ratio <= 1.0015).all(), ratio
+
+
 def test_driver_writes_exr_files(gpu, tmp_path):
     """The C++ host driver (the restatement of src/main.rs) end to end at a small size."""
     exe = os.path.join(gpu.ROOT, "pt_main")
@@ -1391,8 +1470,14 @@ def test_driver_writes_exr_files(gpu, tmp_path):
     out = subprocess.check_output([exe, "--width=64", "--height=48", "--spp=16", "--noise-threshold=0",
                                    f"--out={a}", f"--out-bayer={b}"], text=True, timeout=120)
     assert "Saved" in out and "Demosaic (AMaZE)" in out and "Exposure multiplier=1.000000" in out
-    rgb, dem = gpu.read_exr(a), gpu.read_exr(b)
+    import exr_reader  # a parser of the file layout that shares nothing with the writer
+    rgb, dem = exr_reader.read_rgb(a)[0], exr_reader.read_rgb(b)[0]
+    assert np.array_equal(rgb, gpu.read_exr(a)) and np.array_equal(dem, gpu.read_exr(b))
     assert rgb.shape == (48, 64, 3) and dem.shape == (48, 64, 3)
+    # pt.exr holds the render itself: the driver's first render call is frame 1 of a fresh renderer
+    L = gpu.lib()
+    L.pt_set_frame(0)
+    assert np.array_equal(rgb, gpu.render_rgb(64, 48, 16))
     assert rgb[:, :1].max() == 0 and rgb.mean() > 0.05 and dem.mean() > 0.05
     assert abs(dem.mean() - rgb.mean()) / rgb.mean() < 0.2
     # the reference's defaults (adaptive sampling on) with the guiding loop: train, update, snapshot, render
@@ -1633,6 +1718,6 @@ def test_full_size_1080p_properties(gpu):
     ref = np.load(os.path.join(GOLD, "converge_96x54_spp4096_frame1.npz"))["rgb"]
     assert np.all(np.abs(img.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1)) < 0.02)
     small = img.reshape(54, 20, 96, 20, 3).mean(axis=(1, 3))
-    assert rel_rmse(small, ref) < 0.12
+    assert rel_rmse(small, ref) < 0.06
     L.pt_set_frame(0)
     assert np.array_equal(img, gpu.render_rgb(w, h, spp))  # deterministic

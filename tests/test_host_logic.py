@@ -457,6 +457,31 @@ def test_exr_round_trip(pt, tmp_path):
     assert pt.lib().pt_write_exr(b"/nonexistent_dir/x.exr", 1, 1, P(np.zeros(3, np.float32)), 1.0) == -1
 
 
+def test_exr_file_parsed_by_an_independent_reader(pt, tmp_path):
+    """The file the writer produces, read by a parser that shares nothing with it (tests/exr_reader.py: the
+    OpenEXR single-part scanline layout unpacked field by field): magic and version, the eight required
+    attributes with their types and sizes, channels B, G, R as 32-bit floats in alphabetical order, no
+    compression, an offset table that points at one chunk per scanline, chunks that fill the file exactly --
+    and the pixel values, bit for bit, with the exposure applied (src/main.rs:420-435)."""
+    import struct
+    import exr_reader
+    rng = np.random.default_rng(3)
+    for (h, w) in [(1, 1), (2, 7), (54, 96)]:
+        img = rng.uniform(0, 20, (h, w, 3)).astype(np.float32)
+        img[0, 0] = (0.0, np.float32(1e-30), np.float32(6.5e4))  # values a half-float file would not hold
+        path = str(tmp_path / f"i_{w}x{h}.exr")
+        for exposure in (1.0, 0.25):
+            assert pt.write_exr(path, img, exposure) == 0
+            back, attrs = exr_reader.read_rgb(path)
+            assert back.shape == (h, w, 3)
+            assert np.array_equal(back.view(np.uint32), (img * np.float32(exposure)).view(np.uint32))
+        assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, w - 1, h - 1) == struct.unpack("<4i", attrs["displayWindow"][1])
+        assert struct.unpack("<f", attrs["pixelAspectRatio"][1]) == (1.0,) and attrs["lineOrder"][1] == b"\0"
+        assert [c[:2] for c in exr_reader.parse_channels(attrs["channels"][1])] == [("B", 2), ("G", 2), ("R", 2)]
+        # ... and the two readers agree
+        assert np.array_equal(pt.read_exr(path), back)
+
+
 def _decode_png(raw):
     """A PNG decoder for the files under test: chunks with checked CRCs, one zlib stream, filters 0-2, RGB 8/16."""
     import struct
