@@ -135,6 +135,9 @@ def main():
         large_scene_child()
         return
 
+    if os.environ.get("BENCH_TRACE"):  # debugging aid: dump every thread's stack to stderr every BENCH_TRACE seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_TRACE"]), repeat=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,12 +219,13 @@ def main():
     extra = {}
     if world > 1:
         # the collective alone: the step's one all-reduce of the per-pixel sums, timed by itself
+        # (one at a time, as the step issues it: gloo, the rehearsal backend, stalls on several queued device all-reduces)
         sync()
         t0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(5):
             dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize(dev)
-        ar = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(dev)
+        ar = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64, device=dev)
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
         extra["allreduce_ms"] = float(ar[0])
         extra["allreduce_bytes"] = sums.numel() * 4

@@ -9,7 +9,7 @@ namespace pt {
 
 // Device counters (uint32 words) shared by the wavefront kernels.
 // CNT_EXTEND / CNT_OCCLUDE: how much of the queue the waves of k_extend / k_occlude have taken so far (k_generate clears both)
-enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_SHADOW = 2, CNT_EXTEND = 3, CNT_OCCLUDE = 4, CNT_WORDS = 8 };
+enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_SHADOW = 2, CNT_EXTEND = 3, CNT_OCCLUDE = 4, CNT_Q2 = 5, CNT_WORDS = 8 };
 
 // Everything a wavefront kernel needs, passed by value (lives in the kernarg segment).
 struct RenderParams {
@@ -74,7 +74,15 @@ void launch_shade(const RenderParams& p, int q, const LaunchCfg& c);
 void launch_occlude(const RenderParams& p, int q, const LaunchCfg& c);
 // Fused: up to `bounces` bounces per path in registers, regenerating finished samples in place.
 // compact: append survivors to queue qin^1 (the caller swaps), else process queue qin in place.
-void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, const LaunchCfg& c);
+// The length of queue qin is read from counters[cnt.in]; a compacting launch counts its survivors in counters[cnt.out],
+// which must be zero when it starts; every launch zeroes counters[cnt.clear] (a counter it neither reads nor writes).
+// The fused launches of a render rotate through CNT_Q0, CNT_Q1, CNT_Q2, so that every launch can compact without a
+// memset in between: the one after it appends to the counter this one cleared.
+struct QueueCounters {
+  int in, out, clear;
+};
+inline int next_queue_counter(int c) { return c == CNT_Q0 ? CNT_Q1 : (c == CNT_Q1 ? CNT_Q2 : CNT_Q0); }
+void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, QueueCounters cnt, const LaunchCfg& c);
 
 // Adaptive sampling: active-pixel lists (ping-pong), the 3x3-dilated noise map and each pixel's own noise.
 struct AdaptiveBuffers {
@@ -97,6 +105,8 @@ void launch_expand_active(const uint32_t* active, uint32_t n_active, int chunks,
 void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, int chunks, float* stats, uint32_t npx, hipStream_t s);
 void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx, hipStream_t s);
 
+// resident blocks per CU of the fused kernel launch_bounce picks for p (unguided, no training ring), and its LDS bytes
+int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out);
 // profiling build (-DPT_PROFILE) only: section counters, (waves, lanes) pairs; returns the number of sections
 int read_profile_counters(unsigned long long* out64);
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);

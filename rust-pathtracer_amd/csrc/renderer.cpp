@@ -9,6 +9,7 @@
 #include "pt_guiding.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,11 +44,12 @@ std::vector<State*> g_shards;    // shards 1, 2, ... (shard 0 is g_handle)
 std::mutex g_stats_mutex;        // ray totals are added from every shard's host thread
 KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
-int g_fused_bounces = 16;
+int g_fused_bounces = 32;  // bounces per fused launch (1080p, 1024 spp: 16 389.7 ms, 24 382.0, 32 382.7, 48 382.2, 64 388.4)
 int g_defer_shadow = getenv("PT_DEFER_SHADOW") ? atoi(getenv("PT_DEFER_SHADOW")) : 1;
 int g_adaptive_round = getenv("PT_ADAPTIVE_ROUND") ? atoi(getenv("PT_ADAPTIVE_ROUND")) : -32;
 int g_adaptive_chunks = getenv("PT_ADAPTIVE_CHUNKS") ? atoi(getenv("PT_ADAPTIVE_CHUNKS")) : 0;  // 0: as many as fit
-constexpr size_t kTargetSlots = 8u << 20;  // path slots worth keeping in flight (pixels x chunks)
+constexpr size_t kTargetSlots = 8u << 20;       // path slots a renderer starts with (pixels x chunks); adaptive renders stay within them
+constexpr size_t kFusedTargetSlots = 32u << 20;  // ... and what a fixed-count render of a scene that runs fused grows to
 
 int env_choice(const char* name, const char* a, const char* b, int dflt) {
   const char* v = getenv(name);
@@ -336,8 +338,9 @@ int fit_chunks(State& s, int chunks) {
 constexpr size_t kFusedTreeBytes = (size_t)256u << 10;
 bool staged_by_default(const State& s) { return s.scene.inst_records != nullptr || s.bvh_bytes > kFusedTreeBytes; }
 
-// Chunks (slots per pixel) of a fixed-count render.  Scenes that run fused keep about 8 M slots in flight in
-// chunks of at least 32 samples.  Scenes that run staged (larger trees, instances) do better the more of
+// Chunks (slots per pixel) of a fixed-count render.  Scenes that run fused keep up to 32 M slots in flight in up to
+// 16 chunks of at least 32 samples (1080p, 1024 spp, with the queue compacted by every launch: 8 M slots 404.7 ms,
+// 16 M 395.7, 32 M 390.2: the more slots, the later the launches run out of full waves).  Scenes that run staged (larger trees, instances) do better the more of
 // their samples are in flight at once -- every launch is one bounce of every live path, so fewer, larger launches
 // leave fewer half-empty waves behind: up to 64 chunks of as little as one sample, 144 M slots (22 GB of the
 // GPU's 288) at most and never more than a quarter of what is free.  The state arrays grow when a render needs it.
@@ -346,8 +349,9 @@ int planned_chunks(size_t px, int sample_count, bool staged_scene) {
   static const size_t target_env = getenv("PT_TARGET_SLOTS") ? (size_t)atoll(getenv("PT_TARGET_SLOTS")) : 0;
   static const int min_chunk_env = getenv("PT_MIN_CHUNK_SAMPLES") ? std::max(atoi(getenv("PT_MIN_CHUNK_SAMPLES")), 1) : 0;
   px = std::max<size_t>(px, 1);
-  const int most = staged_scene ? 64 : 16;
-  const size_t target = target_env ? target_env : (staged_scene ? (size_t)144 << 20 : kTargetSlots);
+  static const int most_env = getenv("PT_MAX_CHUNKS") ? atoi(getenv("PT_MAX_CHUNKS")) : 0;
+  const int most = most_env > 0 ? most_env : (staged_scene ? 64 : 16);
+  const size_t target = target_env ? target_env : (staged_scene ? (size_t)144 << 20 : kFusedTargetSlots);
   const int min_chunk = min_chunk_env ? min_chunk_env : (staged_scene ? 1 : 32);
   int chunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)most, target / px));
   if (chunk_override > 0) chunks = std::min(chunk_override, most);
@@ -570,20 +574,28 @@ struct RenderLoop {
     static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
     bool use_fused = fused;
     int qin = 0, slot = 0;
-    int live[2] = {0, 0};  // per read-back slot: the queue that held the live slots when it was taken
+    int cin = CNT_Q0;      // the counter that holds the length of queue[qin] (the staged kernels keep it in counters[qin])
+    int live[2] = {0, 0};  // per read-back slot: the counter that held the number of live slots when it was taken
     bool have_prev = false;
     for (;;) {
       const int iters_per_batch = use_fused ? 8 : 16;
       for (int b = 0; b < iters_per_batch; ++b, ++iter) {
         const bool timed = !s.borrowed && g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
         if (use_fused) {
-          // compact the slot queue every compact_every launches (a divisor of the batch length)
-          // (at least 2: a launch that does not compact clears the counter the next compaction appends to)
-          static const int compact_every = getenv("PT_COMPACT_EVERY") ? std::max(atoi(getenv("PT_COMPACT_EVERY")), 2) : 8;
+          // The slot queue is compacted by every launch (PT_COMPACT_EVERY=n: by every n-th, a divisor of the batch
+          // length): a finished slot left in the queue costs more than its state read -- it idles a lane of a wave
+          // that runs all its bounces for the live slots beside it.  Adaptive renders, whose every round ends with
+          // such a tail, gain 5 %, a fixed-count render 1 %.
+          static const int compact_every = getenv("PT_COMPACT_EVERY") ? std::max(atoi(getenv("PT_COMPACT_EVERY")), 1) : 1;
           const int compact = ((b + 1) % compact_every == 0 || b == iters_per_batch - 1) ? 1 : 0;
+          const int cout = next_queue_counter(cin);
+          const QueueCounters cnt{cin, cout, compact ? next_queue_counter(cout) : cout};
           Timer t(s, PT_K_BOUNCE, timed, 0);
-          launch_bounce(p, qin, std::max(fused_bounces, 1), compact, cfg_fused);
-          if (compact) qin ^= 1;
+          launch_bounce(p, qin, std::max(fused_bounces, 1), compact, cnt, cfg_fused);
+          if (compact) {
+            qin ^= 1;
+            cin = cout;
+          }
           continue;
         }
         { Timer t(s, PT_K_GENERATE, timed, 0); launch_generate(p, qin, cfg); }
@@ -591,19 +603,20 @@ struct RenderLoop {
         { Timer t(s, PT_K_SHADE, timed, 0); launch_shade(p, qin ^ 1, cfg); }
         { Timer t(s, PT_K_OCCLUDE, timed, 0); launch_occlude(p, qin ^ 1, cfg); }
         qin ^= 1;
+        cin = qin;  // CNT_Q0 / CNT_Q1; the other one has been cleared by k_occlude, CNT_Q2 is untouched
       }
-      // Only the counter of the queue the next launch reads says how many slots are live: the other one
-      // still holds the previous length until a later launch clears it.
+      // Only the counter of the queue the next launch reads says how many slots are live: the others
+      // hold earlier lengths until a later launch clears them.
       if (s.borrowed) {  // no pinned memory and no events: a blocking copy after every batch
         uint32_t c[CNT_WORDS];
         HIP_CHECK(hipMemcpy(c, s.counters, sizeof(c), hipMemcpyDeviceToHost));
-        if (c[qin] == 0u) break;
+        if (c[cin] == 0u) break;
         continue;
       }
       HIP_CHECK(hipMemcpyAsync(s.h_counters + slot * CNT_WORDS, s.counters, CNT_WORDS * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, s.stream));
       HIP_CHECK(hipEventRecord(s.ev_slot[slot], s.stream));
-      live[slot] = qin;
+      live[slot] = cin;
       if (have_prev) {
         const int prev = slot ^ 1;
         HIP_CHECK(hipEventSynchronize(s.ev_slot[prev]));
@@ -736,6 +749,10 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
   uint32_t n_active = npx;
   int which = 0, done = 0, done_local = 0, rc = 0;
   s.adaptive_rounds = 0;
+  static const bool trace_rounds = getenv("PT_ADAPTIVE_TRACE") != nullptr;  // per-round wall times on stderr
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_round = 0.0;
+  if (trace_rounds) { HIP_CHECK(hipStreamSynchronize(s.stream)); t_round = now_ms(); }
   while (n_active > 0 && done < total) {
     int target = next_target(done);
     while (target < min_samples && target < total) target = next_target(target);  // no test before min_samples
@@ -765,6 +782,12 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
     HIP_CHECK(hipMemcpyAsync(s.h_counters + 2 * CNT_WORDS, s.adaptive.count, sizeof(uint32_t), hipMemcpyDeviceToHost,
                              s.stream));
     HIP_CHECK(hipStreamSynchronize(s.stream));
+    if (trace_rounds) {
+      const double t = now_ms();
+      fprintf(stderr, "[pt_hip] adaptive round to %d samples: %u pixels x %d chunks, %.2f ms, %u stay active\n", done, n_active,
+              chunks, t - t_round, s.h_counters[2 * CNT_WORDS]);
+      t_round = t;
+    }
     n_active = s.h_counters[2 * CNT_WORDS];
     which ^= 1;
   }
@@ -1415,6 +1438,17 @@ int pt_dbg_profile_counters(uint64_t* out64) {
   HIP_CHECK(hipSetDevice(g_handle->device));
   HIP_CHECK(hipStreamSynchronize(g_handle->stream));
   return read_profile_counters(reinterpret_cast<unsigned long long*>(out64));
+}
+int pt_dbg_fused_occupancy(int adaptive, unsigned long long* lds_bytes) {
+  if (!g_handle) return -1;
+  State& s = *g_handle;
+  HIP_CHECK(hipSetDevice(s.device));
+  RenderParams p = make_params(s, 0, 64, 32, 1, false, false);
+  if (adaptive) p.acc2 = reinterpret_cast<q4*>(s.st_o);  // only tested for being set
+  size_t lds = 0;
+  const int n = bounce_occupancy(p, 256, &lds);
+  if (lds_bytes) *lds_bytes = lds;
+  return n;
 }
 double pt_last_render_ms(void) { return g_handle ? g_handle->last_render_ms : 0.0; }
 int pt_last_render_chunks(void) { return g_handle ? g_handle->last_chunks : 0; }

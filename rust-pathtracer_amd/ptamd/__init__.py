@@ -109,6 +109,7 @@ SIGNATURES = {
     "pt_last_render_chunks": (C.c_int, []),
     "pt_dbg_chunk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong]),
     "pt_dbg_profile_counters": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "pt_dbg_fused_occupancy": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "pt_set_defer_shadow": (None, [C.c_int]),
     "pt_get_defer_shadow": (C.c_int, []),
     "pt_set_adaptive_round": (None, [C.c_int]),

@@ -22,6 +22,19 @@ def rel_rmse(img, ref):
     return float(np.sqrt(np.mean(((img - ref) / (ref + 0.01)) ** 2)))
 
 
+def tent_downsample(img, f):
+    """Image reduced f times per axis with the triangle filter that the renderer's pixel jitter is (sample_tri,
+    optix_device.cu:187-196: a tent of one pixel to either side): what a render f times smaller of the same view
+    converges to, which a plain block mean is not (it differs along every edge in the picture)."""
+    def weights(n_hi):
+        n_lo = n_hi // f
+        x = (np.arange(n_hi) + 0.5) / f
+        w = np.maximum(0.0, 1.0 - np.abs(x[None, :] - (np.arange(n_lo) + 0.5)[:, None]))
+        return (w / f).astype(np.float32)
+    a = np.tensordot(weights(img.shape[0]), img, axes=(1, 0))           # rows
+    return np.moveaxis(np.tensordot(weights(img.shape[1]), a, axes=(1, 1)), 0, 1)  # columns
+
+
 def rel_rmse_trimmed(img, ref, drop=0.002):
     """rel_rmse without the largest `drop` of the squared relative errors: for estimators with a heavy tail (the
     guided branch), where one firefly in either image is most of the plain figure (0.37 against 0.15 without)."""
@@ -1107,12 +1120,12 @@ def test_adaptive_sampling_matches_oracle(gpu, oracle, pipeline):
     # black side bars stop at the first test (their noise is 0)
     assert (counts[:, 0] == mn).all() and (o_counts[:, 0] == mn).all()
     same = (counts == o_counts).mean()
-    assert same > 0.7, same
+    assert same > 0.95, same  # measured 0.979 (0.986 with doubling rounds)
     assert abs(counts.mean() - o_counts.mean()) / o_counts.mean() < 0.05
     assert abs((rr + rs) - sum(o_rays)) / sum(o_rays) < 0.05
     assert abs(img.mean() - o_img.mean()) / o_img.mean() < 0.05  # early stops make the mean firefly-sensitive
     close = (np.abs(img - o_img) <= 2e-3 + 2e-2 * np.abs(o_img)).all(axis=2).mean()
-    assert close > 0.6, close
+    assert close > 0.7, close  # measured 0.75: the pixels whose counts differ, and single bright samples
     # doubling rounds (the default): 32, 64, 128, 256
     L.pt_set_adaptive_round(-32)
     L.pt_set_frame(0)
@@ -1121,7 +1134,7 @@ def test_adaptive_sampling_matches_oracle(gpu, oracle, pipeline):
     o2 = oracle.render(w, h, spp, frame=1, noise_threshold=thr, min_adaptive=mn, mode=oracle.CONVERGE,
                        adaptive_deterministic=1, adaptive_round=-32)[2]
     assert set(np.unique(c2)) <= {32, 64, 128, 256} and r2 <= 4
-    assert (c2 == o2).mean() > 0.7
+    assert (c2 == o2).mean() > 0.95
     L.pt_set_adaptive_round(rnd)
     # threshold so high that every pixel stops at the first test; so low that none stops
     L.pt_set_frame(0)
@@ -1393,7 +1406,7 @@ def test_bayer_render_and_demosaic_chain_at_full_size(gpu):
     oracle's converged 96 x 54 image of the same view (same aspect, so a block is a pixel of it)."""
     import torch
     L = gpu.lib()
-    w, h, spp = 3840, 2160, 16
+    w, h, spp = 3840, 2160, 256  # (the first sample of a pixel's stream is ~9 % bright, D12: 2 % of a 16-spp mean)
     L.pt_set_frame(1)  # -> frame 2, the frame of the reference's Bayer call
     raw = gpu.render_bayer(w, h, spp, pattern=0)
     L.pt_set_frame(1)
@@ -1414,22 +1427,24 @@ def test_bayer_render_and_demosaic_chain_at_full_size(gpu):
     assert np.isfinite(dem).all() and dem.min() >= 0
     assert np.array_equal(dem[0::2, 1::2, 1], raw[0::2, 1::2]) and np.array_equal(dem[1::2, 0::2, 1], raw[1::2, 0::2])
     assert dem[:, :496].max() == 0 and dem[:, -496:].max() == 0
-    # against the oracle's converged image: a 40 x 40 block of the 4K frame is one pixel of the 96 x 54 golden
+    # against the oracle's converged image: the 4K frame reduced 40 times with the pixel filter is the 96 x 54 golden
+    # (its outermost pixels aside, where the reference clamps the jittered position to the image)
     ref = np.load(os.path.join(GOLD, "converge_96x54_spp4096_frame1.npz"))["rgb"]
-    blocks = lambda a: a.reshape(54, 40, 96, 40, -1).mean(axis=(1, 3))
-    dem_b, rgb_b = blocks(dem), blocks(rgb)
-    lit = ref.sum(axis=2) > 0.05
-    for img_b, tol_med, tol_rmse in ((rgb_b, 0.02, 0.06), (dem_b, 0.02, 0.07)):
-        rel = np.abs(img_b - ref)[lit] / (ref[lit] + 0.01)
+    dem_b, rgb_b = tent_downsample(dem, 40), tent_downsample(rgb, 40)
+    inner = (slice(1, -1), slice(1, -1))
+    lit = ref[inner].sum(axis=2) > 0.05
+    # (what is left at 256 spp over 1600 pixels is the 4096-spp golden's own noise, 0.029 per pixel)
+    for img_b, tol_med, tol_rmse in ((rgb_b, 0.03, 0.05), (dem_b, 0.03, 0.055)):
+        rel = np.abs(img_b[inner] - ref[inner])[lit] / (ref[inner][lit] + 0.01)
         assert np.median(rel) < tol_med, np.median(rel)
-        assert rel_rmse(img_b, ref) < tol_rmse, rel_rmse(img_b, ref)
+        assert rel_rmse(img_b[inner], ref[inner]) < tol_rmse, rel_rmse(img_b[inner], ref[inner])
     for c in range(3):
-        assert abs(dem[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.02
-        assert abs(rgb[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.01
+        assert abs(dem[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.012
+        assert abs(rgb[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.004
     # the mosaic's own channel planes (quarter resolution each) against the golden's channels
     for (dy, dx, c) in ((0, 0, 0), (0, 1, 1), (1, 0, 1), (1, 1, 2)):
         plane = raw[dy::2, dx::2].reshape(54, 20, 96, 20).mean(axis=(1, 3))
-        assert abs(plane.mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.01
+        assert abs(plane.mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.005
 
 
 def test_rays_that_start_on_a_plane_keep_their_small_known_bias(gpu):
@@ -1717,7 +1732,7 @@ def test_full_size_1080p_properties(gpu):
     # the image mean agrees with the oracle's converged 96x54 image of the same view
     ref = np.load(os.path.join(GOLD, "converge_96x54_spp4096_frame1.npz"))["rgb"]
     assert np.all(np.abs(img.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) / ref.mean(axis=(0, 1)) < 0.02)
-    small = img.reshape(54, 20, 96, 20, 3).mean(axis=(1, 3))
-    assert rel_rmse(small, ref) < 0.06
+    small = tent_downsample(img, 20)  # the pixel filter of a 96 x 54 render of the same view
+    assert rel_rmse(small[1:-1, 1:-1], ref[1:-1, 1:-1]) < 0.06
     L.pt_set_frame(0)
     assert np.array_equal(img, gpu.render_rgb(w, h, spp))  # deterministic
