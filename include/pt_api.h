@@ -41,7 +41,9 @@ extern "C" {
  * global frame counter (983), so consecutive calls use different seeds.
  * noise_threshold == 0 disables adaptive sampling.  noise_threshold > 0 runs the noise
  * test of optix_device.cu:1011-1060 in a scheduling-independent form: see
- * pt_set_adaptive_round below. */
+ * pt_set_adaptive_round below.
+ * max_depth is clamped to [1, 255] (the path state keeps the depth in 8 bits; the reference
+ * takes any int, its own host passes 32: src/main.rs:481). */
 PT_EXPORT int optix_render_rgb(int w, int h, int spp, int max_depth, float noise_threshold,
                                int min_adaptive_samples, float* out_rgb);
 
@@ -150,7 +152,8 @@ PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
  * and traces them 64 at a time, at full occupancy of the wave; a slot's total is the same set of
  * terms added in a different order, so images agree with the staged pipeline to rounding (same
  * paths).  off: shadow rays are traced where they are made and the two pipelines agree bit for bit.
- * Adaptive renders always trace in place (the noise test needs per-sample sums). */
+ * Adaptive renders always trace in place (the noise test needs per-sample sums; a queued form that kept them
+ * was measured 10 % slower than tracing in place). */
 PT_EXPORT void pt_set_defer_shadow(int on);
 PT_EXPORT int  pt_get_defer_shadow(void);
 
@@ -164,8 +167,12 @@ PT_EXPORT void pt_set_device(int device);
  * renders through pt_render_accumulate_device -- on GPUs first, first + 1, ... (modulo the number of GPUs: more
  * shards than GPUs is allowed and changes only the speed), one host thread per shard; the shards' per-pixel totals
  * are copied to the first GPU (peer copies over xGMI), added there in shard order and divided by the samples
- * taken, so a caller of optix_render_rgb sees one image and nothing else changes.  Adaptive renders stop each
- * shard's pixels on the shard's own statistics.  Scene, camera, Bayer pattern and guiding snapshot are replicated;
+ * taken, so a caller of optix_render_rgb sees one image and nothing else changes.  Adaptive renders are sharded
+ * too, with ONE noise test: at every round boundary the shards meet, the first GPU adds the peers' per-pixel
+ * statistics (sum, samples, sum of squares: 32 bytes per pixel, peer copies) to its own in shard order and hands the
+ * totals back, so noise_threshold and min_adaptive_samples mean what they mean on one GPU and every shard keeps the
+ * same pixels active (a shard takes its proportional part of every round, rounded up; pt_get_sample_counts then
+ * reports the totals of all shards).  Scene, camera, Bayer pattern and guiding snapshot are replicated;
  * guiding_map_train_samples returns the records of all shards' rings.  Strict mode is never sharded. */
 PT_EXPORT void pt_set_device_count(int n);
 PT_EXPORT int  pt_get_device_count(void);
@@ -184,8 +191,10 @@ PT_EXPORT int  pt_get_frame(void);
  * per-pixel PCG stream, so G chunks on one GPU equal G ranks with one chunk each. */
 PT_EXPORT int pt_render_accumulate_device(int w, int h, int sample_begin, int sample_count, int max_depth,
                                           int frame, float* d_sum_rgb);
-/* pt_render_accumulate_device for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+/* pt_render_accumulate_device for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Not a call that can be recorded into a HIP graph: it runs
+ * on the null stream and synchronises the device several times per render (a blocking read-back of the live-slot
+ * counter after every batch of launches, and once more at the end), and its first call on a device copies the scene.  Same arguments, same
  * result bit for bit (same scene, default camera, fused pipeline), but every byte of device memory besides
  * d_sum_rgb -- path state, slot queues, counters, the scene -- lives in one static array of the library's code
  * object (PT_NOALLOC_MAX_SLOTS * 92 + PT_NOALLOC_MAX_SCENE_BYTES + 512 bytes = 24.2 MB, held by every GPU the
@@ -337,6 +346,14 @@ PT_EXPORT void pt_pgl_samples_add_batch(pgl_samples_t samples, const TrainSample
 #define PT_PGL_BIN_LOBES 6
 #define PT_PGL_BIN_WORDS 8
 #define PT_PGL_BIN_SHIFT 24
+/* What the fixed-point table represents exactly, and therefore what both forms of the trainer accept: a training
+ * record is used when its weight (the mean of contrib) lies in [PT_PGL_MIN_WEIGHT, PT_PGL_MAX_WEIGHT] and no
+ * component of contrib exceeds PT_PGL_MAX_WEIGHT in magnitude; any other record (a firefly of 1e12, a weight that
+ * would round to zero steps of 2^-24, a NaN) is dropped by pgl_field_update and by the binning kernel alike, so the
+ * two never diverge.  A bin then holds 2^19 records of the largest weight before its 64-bit sum could wrap; the
+ * training ring holds 2^18. */
+#define PT_PGL_MAX_WEIGHT 1048576.0f          /* 2^20 */
+#define PT_PGL_MIN_WEIGHT 2.98023223876953125e-8f /* 2^-25: half a step of the table */
 PT_EXPORT int  pt_pgl_field_layout(pgl_field_t field, float bmin[3], float bmax[3], int res[3], float* lobe_axes,
                                    uint32_t* regions);
 PT_EXPORT void pt_pgl_field_update_binned(pgl_field_t field, const long long* bins);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/pt_api.h"
+#include "pt_guiding.h"
 
 namespace {
 
@@ -130,7 +131,7 @@ void pgl_field_update(pgl_field_t field_handle, pgl_samples_t samples_handle) {
       c[k] = (int)((it.pos[k] - f->bmin[k]) / ext * (float)f->res[k]);
       if (c[k] >= f->res[k]) c[k] = f->res[k] - 1;
     }
-    if (!inside || !(it.weight > 0.f) || !std::isfinite(it.weight)) continue;
+    if (!inside || !pt::train_weight_usable(it.weight, it.rgb)) continue;  // the same records the binning kernel uses
     StubRegion& reg = f->regions[((size_t)c[2] * f->res[1] + c[1]) * f->res[0] + c[0]];
     int best = 0;
     float best_d = -2.f;

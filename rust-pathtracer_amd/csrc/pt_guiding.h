@@ -131,9 +131,18 @@ struct BinField {
   int res[3];
 };
 constexpr int kBinLobes = 6, kBinWords = 8, kBinShift = 24;
+// Records the trainer uses: weight in [2^-25, 2^20], no colour component beyond 2^20 in magnitude -- what the table's
+// 2^-24 steps and 64-bit sums hold exactly (a bin takes 2^19 records of the largest weight before it could wrap).
+constexpr float kTrainMaxWeight = 1048576.0f, kTrainMinWeight = 2.98023223876953125e-8f;
+PT_HD bool train_weight_usable(float weight, const float contrib[3]) {
+  if (!(weight >= kTrainMinWeight) || !(weight <= kTrainMaxWeight)) return false;  // a NaN fails both
+  for (int k = 0; k < 3; ++k)
+    if (!(fabsf(contrib[k]) <= kTrainMaxWeight)) return false;
+  return true;
+}
 
 // One ring record -> the (region, lobe) it trains and its eight fixed-point addends; false when the trainer would
-// drop it (torn or empty slot, outside the field, weight not positive and finite).  The assignment repeats the
+// drop it (torn or empty slot, outside the field, weight or colour outside the range the table holds exactly).  The assignment repeats the
 // trainer's own float arithmetic operation for operation (no fused multiply-adds), so both agree on every record.
 PT_HD bool bin_train_record(const TrainRec& rec, const BinField& f, const float* axes, uint32_t& bin, long long add[kBinWords]) {
 #if defined(__clang__)
@@ -148,7 +157,7 @@ PT_HD bool bin_train_record(const TrainRec& rec, const BinField& f, const float*
     if (c[k] >= f.res[k]) c[k] = f.res[k] - 1;
   }
   const float weight = (rec.contrib[0] + rec.contrib[1] + rec.contrib[2]) / 3.0f;
-  if (!(weight > 0.f) || !(weight <= 3.4028234663852886e38f)) return false;
+  if (!train_weight_usable(weight, rec.contrib)) return false;
   const uint32_t region = (uint32_t)((c[2] * f.res[1] + c[1]) * f.res[0] + c[0]);
   const float* mu = axes + (size_t)region * kBinLobes * 3;
   int best = 0;

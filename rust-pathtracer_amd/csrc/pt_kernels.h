@@ -105,6 +105,9 @@ void launch_expand_active(const uint32_t* active, uint32_t n_active, int chunks,
 void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, int chunks, float* stats, uint32_t npx, hipStream_t s);
 void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx, hipStream_t s);
 
+// packed statistics (8 floats per pixel): own += peer over n floats; mean image = sum / samples taken
+void launch_add_stats(float* own, const float* peer, size_t n, hipStream_t s);
+void launch_stats_mean(const float* stats, float* out_rgb, uint32_t npx, hipStream_t s);
 // resident blocks per CU of the fused kernel launch_bounce picks for p (unguided, no training ring), and its LDS bytes
 int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out);
 // profiling build (-DPT_PROFILE) only: section counters, (waves, lanes) pairs; returns the number of sections

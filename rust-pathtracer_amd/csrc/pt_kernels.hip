@@ -979,6 +979,19 @@ __global__ void k_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count
   }
 }
 
+// In-library sample shards of an adaptive render: add a peer's packed statistics to this shard's, and the mean image
+// of the finished render from the totals.
+__global__ void k_add_stats(float* own, const float* peer, size_t n) {
+  for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) own[i] += peer[i];
+}
+__global__ void k_stats_mean(const float* stats, float* out, uint32_t npx) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+    const q4 a = reinterpret_cast<const q4*>(stats)[2 * (size_t)i];
+    const float inv = a.w > 0.0f ? 1.0f / a.w : 0.0f;
+    out[3 * i + 0] = a.x * inv; out[3 * i + 1] = a.y * inv; out[3 * i + 2] = a.z * inv;
+  }
+}
+
 // ------------------------------------------------------------------------ utilities
 __global__ void k_iota(uint32_t* dst, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = i;
@@ -1137,6 +1150,14 @@ void launch_pack_stats(const q4* acc, const q4* acc2, const int* started, int ch
 }
 void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint32_t npx, hipStream_t s) {
   k_unpack_stats<<<1024, 256, 0, s>>>(stats, acc, acc2, count, npx);
+  PT_KCHECK();
+}
+void launch_add_stats(float* own, const float* peer, size_t n, hipStream_t s) {
+  k_add_stats<<<1024, 256, 0, s>>>(own, peer, n);
+  PT_KCHECK();
+}
+void launch_stats_mean(const float* stats, float* out_rgb, uint32_t npx, hipStream_t s) {
+  k_stats_mean<<<1024, 256, 0, s>>>(stats, out_rgb, npx);
   PT_KCHECK();
 }
 void launch_noise_round(const AdaptiveBuffers& a, int which, uint32_t n_active, const q4* acc, const q4* acc2,

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -833,38 +834,111 @@ State& ensure_shard(int d, const State& first) {
   return *sh;
 }
 
+// A meeting point for the shards' host threads (C++17 has no std::barrier).
+struct ThreadBarrier {
+  std::mutex m;
+  std::condition_variable cv;
+  int n, waiting = 0;
+  uint64_t generation = 0;
+  explicit ThreadBarrier(int count) : n(count) {}
+  void wait() {
+    std::unique_lock<std::mutex> lock(m);
+    const uint64_t g = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return generation != g; });
+    }
+  }
+};
+
 // One render call split by sample index over n shards, one host thread and one GPU each (optix_wrapper.cpp:1102-1115
 // stays the only call the host makes): shard d renders samples [d*spp/n, (d+1)*spp/n) of every pixel exactly as
 // rank d of a multi-process render would, the shards' per-pixel totals are copied to shard 0's GPU and added there in
-// shard order, and shard 0 divides by the number of samples taken.  Adaptive renders stop each shard's pixels on the
-// shard's own statistics.
+// shard order, and shard 0 divides by the number of samples taken.
+// Adaptive renders run ONE noise test on the statistics of all shards together (the progressive reduce of
+// pt_render_adaptive_shared_device, with peer copies in place of a collective): at every round boundary the shards
+// meet, shard 0 adds the peers' packed statistics to its own in shard order and hands the totals back, and every
+// shard keeps the same pixels active -- so min_adaptive_samples and the threshold mean what they mean on one GPU,
+// whatever the number of shards.
 void render_mean_sharded(State& s, int n, int spp, int max_depth, float noise_threshold, int min_adaptive_samples) {
   const uint32_t npx = (uint32_t)((size_t)s.width * (size_t)s.height);
+  const bool adaptive = noise_threshold > 0.0f;
   (void)current_bvh();  // built once, before the threads need it
   std::vector<State*> st((size_t)n);
   st[0] = &s;
   for (int d = 1; d < n; ++d) st[(size_t)d] = &ensure_shard(d, s);
-  for (State* sd : st) {
+  // Everything that allocates happens here, one shard after the other: shards that share a GPU would otherwise each
+  // size their path state for a quarter of the same free memory at the same moment.
+  std::vector<int> on_device((size_t)n, 0);
+  for (int d = 0; d < n; ++d)
+    for (int e = 0; e < n; ++e) on_device[(size_t)d] += st[(size_t)e]->device == st[(size_t)d]->device ? 1 : 0;
+  for (int d = 0; d < n; ++d) {
+    State* sd = st[(size_t)d];
     HIP_CHECK(hipSetDevice(sd->device));
     if (!sd->d_sum4) sd->d_sum4 = dev_alloc<q4>(npx);
-    if (noise_threshold > 0.0f) ensure_adaptive(*sd);
+    if (adaptive) {
+      ensure_adaptive(*sd);
+      if (!sd->d_shard_stats) sd->d_shard_stats = dev_alloc<float>((size_t)npx * 8);
+      HIP_CHECK(hipMemsetAsync(sd->d_shard_stats, 0, (size_t)npx * 8 * sizeof(float), sd->stream));
+    } else {
+      const int begin = (int)((long long)d * spp / n), count = (int)((long long)(d + 1) * spp / n) - begin;
+      const int want = planned_chunks(npx, count, staged_by_default(*sd));
+      fit_chunks(*sd, std::max(1, want / on_device[(size_t)d]));  // its part of what the GPU has room for
+    }
   }
   HIP_CHECK(hipSetDevice(s.device));
-  if (s.peer_capacity < (size_t)(n - 1) * npx) {
+  if (adaptive && !s.d_stats_in) s.d_stats_in = dev_alloc<float>((size_t)npx * 8);
+  if (!adaptive && s.peer_capacity < (size_t)(n - 1) * npx) {
     dev_free(s.d_peer);
     s.peer_capacity = (size_t)(n - 1) * npx;
     s.d_peer = dev_alloc<q4>(s.peer_capacity);
   }
   const int frame = g_frame;
+  ThreadBarrier meet(n);
+  struct ReduceCtx {
+    std::vector<State*>* st;
+    ThreadBarrier* meet;
+    int d, n;
+    uint32_t npx;
+  };
+  // called by every shard's thread once its statistics are packed and its stream is idle
+  auto reduce = [](void* user) -> int {
+    ReduceCtx& c = *static_cast<ReduceCtx*>(user);
+    c.meet->wait();
+    if (c.d == 0) {
+      State& first = *(*c.st)[0];
+      const size_t bytes = (size_t)c.npx * 8 * sizeof(float);
+      HIP_CHECK(hipSetDevice(first.device));
+      for (int e = 1; e < c.n; ++e) {  // shard order: the totals do not depend on which shard arrived first
+        State& peer = *(*c.st)[(size_t)e];
+        HIP_CHECK(hipMemcpyPeerAsync(first.d_stats_in, first.device, peer.d_shard_stats, peer.device, bytes, first.stream));
+        launch_add_stats(first.d_shard_stats, first.d_stats_in, (size_t)c.npx * 8, first.stream);
+      }
+      for (int e = 1; e < c.n; ++e) {
+        State& peer = *(*c.st)[(size_t)e];
+        HIP_CHECK(hipMemcpyPeerAsync(peer.d_shard_stats, peer.device, first.d_shard_stats, first.device, bytes, first.stream));
+      }
+      HIP_CHECK(hipStreamSynchronize(first.stream));
+    }
+    c.meet->wait();
+    return 0;
+  };
+  std::vector<ReduceCtx> ctx((size_t)n);
   auto work = [&](int d) {
     State& sd = *st[(size_t)d];
     HIP_CHECK(hipSetDevice(sd.device));
     const int begin = (int)((long long)d * spp / n), count = (int)((long long)(d + 1) * spp / n) - begin;
-    if (noise_threshold > 0.0f && count > 0)
-      render_adaptive(sd, begin, count, max_depth, frame, false, noise_threshold, min_adaptive_samples, nullptr);
-    else
+    if (adaptive) {
+      ctx[(size_t)d] = ReduceCtx{&st, &meet, d, n, npx};
+      const SharedStats shared{sd.d_shard_stats, spp, reduce, &ctx[(size_t)d]};
+      render_adaptive(sd, begin, count, max_depth, frame, false, noise_threshold, min_adaptive_samples, &shared);
+    } else {
       render_core(sd, begin, count, max_depth, frame, false);
-    launch_shard_sums(sd.acc, sd.started, sd.d_sum4, npx, sd.last_chunks, sd.stream);
+      launch_shard_sums(sd.acc, sd.started, sd.d_sum4, npx, sd.last_chunks, sd.stream);
+    }
     HIP_CHECK(hipStreamSynchronize(sd.stream));
   };
   std::vector<std::thread> threads;
@@ -872,6 +946,11 @@ void render_mean_sharded(State& s, int n, int spp, int max_depth, float noise_th
   work(0);
   for (std::thread& t : threads) t.join();
   HIP_CHECK(hipSetDevice(s.device));
+  s.counts_from_stats = adaptive;
+  if (adaptive) {  // every shard holds the totals of the finished render
+    launch_stats_mean(s.d_shard_stats, s.d_out_rgb, npx, s.stream);
+    return;
+  }
   for (int d = 1; d < n; ++d)
     HIP_CHECK(hipMemcpyPeerAsync(s.d_peer + (size_t)(d - 1) * npx, s.device, st[(size_t)d]->d_sum4, st[(size_t)d]->device,
                                  (size_t)npx * sizeof(q4), s.stream));
@@ -883,6 +962,7 @@ int render_mean(State& s, int spp, int max_depth, float noise_threshold, int min
   const bool strict = mode() == PT_MODE_STRICT;
   // strict mode replays the reference's launches one pixel stream at a time: never sharded
   const int shards = strict ? 1 : std::min(shard_setting(), std::max(spp, 1));
+  s.counts_from_stats = false;
   if (shards > 1) {
     render_mean_sharded(s, shards, spp, max_depth, noise_threshold, min_adaptive_samples);
     return 0;
@@ -988,7 +1068,7 @@ State::~State() {
   dev_free(acc2); dev_free(adaptive.active[0]); dev_free(adaptive.active[1]); dev_free(adaptive.count);
   dev_free(adaptive.noise_map); dev_free(adaptive.own_noise); dev_free(adaptive.total);
   dev_free(shared_acc); dev_free(shared_acc2); dev_free(shared_n);
-  dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_sum4); dev_free(d_peer);
+  dev_free(d_out_rgb); dev_free(d_out_bayer); dev_free(d_sum4); dev_free(d_peer); dev_free(d_shard_stats); dev_free(d_stats_in);
   dev_free(d_train); dev_free(d_train_idx); dev_free(d_regions); dev_free(d_lobes); dev_free(d_grid); dev_free(d_cells);
   if (h_counters) (void)hipHostFree(h_counters);
   for (int i = 0; i < 2; ++i) if (ev_slot[i]) (void)hipEventDestroy(ev_slot[i]);
@@ -1421,7 +1501,11 @@ int pt_get_sample_counts(int* out_counts, int* out_rounds) {
   HIP_CHECK(hipSetDevice(s.device));
   HIP_CHECK(hipStreamSynchronize(s.stream));
   const size_t px = (size_t)s.width * (size_t)s.height;
-  if (out_counts) {
+  if (out_counts && s.counts_from_stats && s.d_shard_stats) {  // sample shards with one noise test: the totals of all shards
+    std::vector<float> tmp(px * 8);
+    HIP_CHECK(hipMemcpy(tmp.data(), s.d_shard_stats, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < px; ++i) out_counts[i] = (int)(tmp[8 * i + 3] + 0.5f);
+  } else if (out_counts) {
     std::vector<int> tmp(px * (size_t)s.last_chunks);
     HIP_CHECK(hipMemcpy(tmp.data(), s.started, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < px; ++i) {

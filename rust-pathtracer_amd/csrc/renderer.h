@@ -86,6 +86,9 @@ struct State {
   q4* d_sum4 = nullptr;
   q4* d_peer = nullptr;
   size_t peer_capacity = 0;  // q4 elements
+  float* d_shard_stats = nullptr;  // in-library sample shards, adaptive: this shard's (sum, n, sum of squares) per pixel, 8 floats
+  float* d_stats_in = nullptr;     // ... on the first shard: a peer's statistics while they are added
+  bool counts_from_stats = false;  // the last render's per-pixel sample counts are the totals in d_shard_stats
   bool quiet = false;
 
   // outputs

@@ -4,6 +4,7 @@ multiply-adds, eight 64-bit fixed-point sums per (region, lobe)."""
 import numpy as np
 
 LOBES, WORDS, SHIFT = 6, 8, 24
+MAX_WEIGHT, MIN_WEIGHT = 2.0 ** 20, 2.0 ** -25  # PT_PGL_MAX_WEIGHT, PT_PGL_MIN_WEIGHT
 
 
 def bin_records(records, bmin, bmax, res, axes):
@@ -19,7 +20,8 @@ def bin_records(records, bmin, bmax, res, axes):
         cell = ((pos - bmin).astype(f32) / ext * res.astype(f32)).astype(f32)
         cell = np.minimum(np.nan_to_num(cell, nan=0.0, posinf=0.0, neginf=0.0).astype(np.int64), res.astype(np.int64) - 1)
         weight = ((rgb[:, 0] + rgb[:, 1]).astype(f32) + rgb[:, 2]).astype(f32) / f32(3.0)
-    ok = inside & (weight > 0) & np.isfinite(weight)
+    with np.errstate(invalid="ignore"):
+        ok = inside & (weight >= f32(MIN_WEIGHT)) & (weight <= f32(MAX_WEIGHT)) & (np.abs(rgb) <= f32(MAX_WEIGHT)).all(1)
     region = (cell[:, 2] * int(res[1]) + cell[:, 1]) * int(res[0]) + cell[:, 0]
     scale = float(1 << SHIFT)
     for i in np.nonzero(ok)[0]:

@@ -1016,11 +1016,28 @@ def test_in_library_shards_equal_the_ranks_they_stand_for(gpu):
         L.pt_set_frame(4)
         few = gpu.render_rgb(w, h, 3)
         assert np.isfinite(few).all() and abs(few.mean() - plain.mean()) / plain.mean() < 0.2
-        # adaptive renders shard too (each shard stops pixels on its own statistics)
-        L.pt_set_device_count(2)
+        # adaptive renders shard too, with ONE noise test on the statistics of all shards together: the threshold and
+        # min_adaptive_samples mean what they mean on one GPU (the black bars stop at 32 samples in all, not at 32 per
+        # shard), counts follow the round schedule of the whole render, and the same pixels stop as in the one-shard
+        # render, up to the noise of different samples
+        L.pt_set_device_count(1)
         L.pt_set_frame(4)
-        ada = gpu.render_rgb(w, h, 256, noise_threshold=0.5, min_adaptive_samples=32)
-        assert np.isfinite(ada).all() and abs(ada.mean() - plain.mean()) / plain.mean() < 0.05
+        one = gpu.render_rgb(w, h, 256, noise_threshold=0.5, min_adaptive_samples=32)
+        c_one, _ = gpu.sample_counts(w, h)
+        for shards in (2, 3):
+            L.pt_set_device_count(shards)
+            L.pt_set_frame(4)
+            ada = gpu.render_rgb(w, h, 256, noise_threshold=0.5, min_adaptive_samples=32)
+            c_ada, rounds = gpu.sample_counts(w, h)
+            assert np.isfinite(ada).all() and abs(ada.mean() - one.mean()) / one.mean() < 0.05
+            # a shard takes its proportional part of every round, rounded up: 16 + 16, or 11 + 11 + 11, at the first test
+            first = 32 if shards == 2 else 33
+            assert c_ada.min() == first and c_ada.max() == 256 and rounds == 4
+            assert (c_ada[:, 0] == first).all() and (shards != 2 or set(np.unique(c_ada)) <= {32, 64, 128, 256})
+            assert (c_ada == c_one).mean() > 0.7, (shards, (c_ada == c_one).mean())
+            L.pt_set_frame(4)
+            again = gpu.render_rgb(w, h, 256, noise_threshold=0.5, min_adaptive_samples=32)
+            assert np.array_equal(ada, again)  # whichever shard's thread arrives first
     finally:
         L.pt_set_device_count(1)
 

@@ -1055,6 +1055,46 @@ def test_trainer_drops_records_that_are_not_numbers(pt):
         f.close()
 
 
+def test_trainer_drops_weights_the_table_cannot_hold(pt, hostcheck):
+    """A firefly of 1e12 would overflow the 64-bit fixed-point sums of the binned form (2^-24 steps) and a weight
+    below half a step would count as a sample of weight zero there, while the record-by-record form works in
+    doubles: both forms drop records outside [PT_PGL_MIN_WEIGHT, PT_PGL_MAX_WEIGHT] (pt_api.h), so the fields they
+    train stay the same field.  Checked on the numpy restatement, on the kernel's per-record body compiled for the
+    host, and on both update calls of the library."""
+    import binning
+    rec = np.zeros((6, 10), np.float32)
+    rec[:, 0:3] = (0.1, 0.2, 0.3)
+    rec[:, 5] = 1.0           # dir_in = +z
+    rec[:, 6:9] = 0.5         # an ordinary record ...
+    rec[1, 6:9] = 1e12        # ... a firefly
+    rec[2, 6:9] = (3e6, 0.0, 0.0)   # mean 1e6 is inside the range, its red component is not
+    rec[3, 6:9] = 1e-9        # rounds to no step of the table
+    rec[4, 6:9] = 2.0 ** 20   # the largest weight that is used
+    rec[5, 6:9] = (-4.0, 1.0, 4.5)  # negative components are fine while the mean is positive
+    used = [0, 4, 5]
+    a, b = pt.GuidingField((-1, -1, 0), (1, 1, 2)), pt.GuidingField((-1, -1, 0), (1, 1, 2))
+    try:
+        lay = a.layout()
+        table = binning.bin_records(rec, *lay)
+        assert table[7::8].sum() == len(used)
+        assert table[3::8].sum() == sum(int(np.rint(float(rec[i, 6:9].astype(np.float32).sum() / np.float32(3)) * 2.0 ** 24)) for i in used)
+        # the device kernel's body, record by record
+        bmin, bmax, res, axes = lay
+        got = np.zeros_like(table)
+        torn = np.zeros(len(rec), np.int32)
+        hostcheck.hc_bin_records(P(rec), len(rec), P(bmin), P(bmax), P(res, C.c_int), P(axes), P(torn, C.c_int),
+                                 got.ctypes.data_as(C.POINTER(C.c_longlong)))
+        assert np.array_equal(got, table)
+        # both update calls train the same field from these records
+        a.update(rec)
+        b.update_binned(table)
+        (ra, la), (rb, lb) = a.snapshot(), b.snapshot()
+        assert np.array_equal(ra, rb) and la.shape == lb.shape and np.allclose(la, lb, rtol=2e-5, atol=2e-6)
+    finally:
+        a.close()
+        b.close()
+
+
 _BINNED_WORKER = r'''
 import sys
 import numpy as np, torch, torch.distributed as dist
