@@ -166,7 +166,7 @@ def main():
     L.pt_set_pipeline(ptamd.PIPELINE_FUSED if args.pipeline == "fused" else ptamd.PIPELINE_STAGED)
     w, h, spp = args.width, args.height, args.spp
     sums = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
-    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    scaling = args.scaling or "strong"  # one 1024-spp frame whatever the number of GPUs (at N = 1 the two modes coincide)
 
     def sync():
         if world > 1:

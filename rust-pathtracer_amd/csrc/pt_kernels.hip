@@ -773,7 +773,13 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
       sr.valid = false;
       if (active) { PT_PROF(PF_BOUNCE); }
       PT_TIC(t_regen);
-      if (active && !(ps.flags & kAlive)) {
+#ifdef PT_X_REGEN_MIN
+      const bool regen_now = (uint32_t)__popcll(__ballot(active && !(ps.flags & kAlive))) >= (uint32_t)PT_X_REGEN_MIN ||
+                             __ballot(active && (ps.flags & kAlive)) == 0ull;
+#else
+      const bool regen_now = true;
+#endif
+      if (regen_now && active && !(ps.flags & kAlive)) {
         PT_PROF(PF_REGEN);
         if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's sum
           q4 acc = p.acc[pixel];
@@ -791,7 +797,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
         }
       }
       PT_TOC(t_regen, PT_T_REGEN);
+#ifdef PT_X_REGEN_MIN
+      if (active && (ps.flags & kAlive)) {
+#else
       if (active) {
+#endif
         rc.s = hash_sample_index(p, sl, local - 1);
         PT_TIC(t_trace);
         const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth, ps.origin);
