@@ -84,7 +84,11 @@ PT_HD float schlick(float cosTheta, float f0) { return f0 + (1.0f - f0) * pow5(f
 PT_HD f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(i, n)); }
 
 // optix_device.cu:285-332
-PT_HD void sample_ggx_vndf(float ux, float uy, float alpha, f3 N, f3 V, f3& L, f3& H, float& pdf) {
+// renormalising a vector that is unit by construction (a unit vector in an orthonormal frame, the mirror image of
+// one) changes its last bit at most: left out
+PT_HD f3 unit_by_construction(f3 v) { return v; }
+// g1v: the Smith term of the view direction, which the caller has already (it depends on N.V and alpha only)
+PT_HD void sample_ggx_vndf(float ux, float uy, float alpha, f3 N, f3 V, f3& L, f3& H, float& pdf, float g1v = -1.0f) {
   f3 T, B;
   make_onb(N, T, B);
   const f3 Vlocal = mk3(dot(V, T), dot(V, B), dot(V, N));
@@ -99,15 +103,15 @@ PT_HD void sample_ggx_vndf(float ux, float uy, float alpha, f3 N, f3 V, f3& L, f
   t2 = (1.0f - s) * fsqrt(fmaxf(0.0f, 1.0f - t1 * t1)) + s * t2;
   const f3 Nh = T1 * t1 + T2 * t2 + Vh * fsqrt(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
   const f3 Hlocal = normalize_chk(mk3(alpha * Nh.x, alpha * Nh.y, fmaxf(0.0f, Nh.z)));
-  H = normalize_chk(T * Hlocal.x + B * Hlocal.y + N * Hlocal.z);
-  L = normalize_chk(reflect(-V, H));
+  H = unit_by_construction(T * Hlocal.x + B * Hlocal.y + N * Hlocal.z);
+  L = unit_by_construction(reflect(-V, H));
   const float NoH = fmaxf(dot(N, H), 0.0f);
   const float NoV = fmaxf(dot(N, V), 0.0f);
   const float VoH = fmaxf(dot(V, H), 0.0f);
   const float alpha2 = alpha * alpha;
   const float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
   const float D = alpha2 * rcp(kPi * denom * denom);
-  const float G1V = 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
+  const float G1V = g1v >= 0.0f ? g1v : 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
   pdf = (D * NoH * G1V) * rcp(4.0f * fmaxf(VoH, 1e-6f));
 }
 
@@ -239,6 +243,9 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
     const f3 kd = Base_colour * (1.0f - F);
     const float alpha = fmaxf(Roughness * Roughness, 1e-4f);
     const float alpha2 = alpha * alpha;
+    // Smith term of the view direction: the same number in next-event estimation, in the sampler's pdf and in the
+    // specular weight (optix_device.cu:531, 328, 577), computed once
+    const float G1V_shared = 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
     const float area = 4.0f * sc.light_half[0] * sc.light_half[1];
     const f3 light_n = ld3(sc.light_normal);
 
@@ -271,7 +278,7 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
         const float NoH = fmaxf(dot(Ng, H), 0.0f);
         const float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
         const float D = alpha2 * rcp(kPi * denom * denom);
-        const float G1V = 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
+        const float G1V = G1V_shared;
         const float G1L = 2.0f * cosS * rcp(cosS + fsqrt(alpha2 + (1.0f - alpha2) * cosS * cosS));
         const float Fh = schlick(VoH, f0);
         const float f_spec = Fh * (D * G1V * G1L * rcp(fmaxf(4.0f * NoV * cosS, 1e-6f)));
@@ -313,13 +320,13 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
       const float uy = next_rand(ps, rc);
       f3 newDir, H;
       float pdf;
-      sample_ggx_vndf(ux, uy, alpha, Ng, V, newDir, H, pdf);
+      sample_ggx_vndf(ux, uy, alpha, Ng, V, newDir, H, pdf, G1V_shared);
       const float NoL = fmaxf(dot(Ng, newDir), 0.0f);
       const float VoH = fmaxf(dot(V, H), 0.0f);
       const float NoH = fmaxf(dot(Ng, H), 0.0f);
       const float denom = NoH * NoH * (alpha2 - 1.0f) + 1.0f;
       const float D = alpha2 * rcp(kPi * denom * denom);
-      const float G1V = 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
+      const float G1V = G1V_shared;
       const float G1L = 2.0f * NoL * rcp(NoL + fsqrt(alpha2 + (1.0f - alpha2) * NoL * NoL));
       const float Fh = schlick(VoH, f0);
       const float spec_brdf = Fh * (D * G1V * G1L * rcp(fmaxf(4.0f * NoV * NoL, 1e-6f)));
@@ -381,7 +388,7 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
         const f3 local = mk3(cos2pi(r1) * sinTheta, sin2pi(r1) * sinTheta, cosTheta);
         f3 tangent, bitangent;
         make_onb(Ng, tangent, bitangent);
-        newDir = normalize_chk(tangent * local.x + bitangent * local.y + Ng * local.z);
+        newDir = unit_by_construction(tangent * local.x + bitangent * local.y + Ng * local.z);
         p_bsdf = cosTheta * kInvPi;
         // (the reference also evaluates the mixture pdf of this direction, optix_device.cu:647, and never uses it)
       }

@@ -154,7 +154,9 @@ PT_HD f3 normalize_chk(f3 v) {
   return l2 > 0.f ? v * rsqrt(l2) : mk3(0.f);
 }
 // optix_device.cu:137-139
-PT_HD f3 normalize3(f3 v) { return v * rcp(fmaxf(length(v), 1e-20f)); }
+// one reciprocal square root in place of a square root and a reciprocal (the two forms agree to an ulp; the guard
+// only matters for vectors shorter than 1e-19, which none of the callers makes)
+PT_HD f3 normalize3(f3 v) { return v * rsqrt(fmaxf(dot(v, v), 1e-38f)); }
 
 PT_HD uint32_t f2u(float f) {
   uint32_t u;

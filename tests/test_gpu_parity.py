@@ -635,21 +635,31 @@ def test_guided_render_parity(gpu, oracle, pipeline):
     regions, lobes = synthetic_snapshot(seed=1234)
     w, h, spp = 64, 48, 512
     G, keep = oracle.make_guide(regions, lobes, (4, 4, 4))
-    ref, _, _, orays = oracle.render(w, h, spp, frame=1, guide=G)
+    refs = [oracle.render(w, h, spp, frame=f, guide=G) for f in (1, 2, 3)]
+    ref, orays = refs[0][0], refs[0][3]
     plain = oracle.render(w, h, spp, frame=1)[0]
     L.guiding_set_grid_res(4, 4, 4)
     gpu.upload_snapshot(regions, lobes)
     L.guiding_set_enabled(1)
     L.pt_set_pipeline(pipeline)
     try:
-        L.pt_set_frame(30)
-        L.pt_reset_ray_counts()
-        img = gpu.render_rgb(w, h, spp)
-        rr, rs = gpu.ray_counts()
+        imgs = []
+        for f in (30, 31, 32, 33):
+            L.pt_set_frame(f)
+            L.pt_reset_ray_counts()
+            imgs.append(gpu.render_rgb(w, h, spp))
+            rr, rs = gpu.ray_counts()
+        img = imgs[0]
     finally:
         L.guiding_set_enabled(0)
         L.pt_set_pipeline(1)
-    assert abs(img.mean() - ref.mean()) / ref.mean() < 0.02
+    # image means: the guided estimator has a heavy tail (weights 1 / pdf of a sharp lobe), so one frame's mean moves
+    # by about a per cent between frames on either side (measured: oracle 0.1249 / 0.1258 / 0.1261, GPU 0.1254 ...
+    # 0.1276); several frames of each are compared, against the spread they show
+    m_gpu, m_ref = np.array([x.mean() for x in imgs]), np.array([r[0].mean() for r in refs])
+    sigma = np.sqrt(m_gpu.var(ddof=1) / len(m_gpu) + m_ref.var(ddof=1) / len(m_ref))
+    assert abs(m_gpu.mean() - m_ref.mean()) < 3 * sigma + 0.005 * m_ref.mean(), (m_gpu, m_ref)
+    assert abs(img.mean() - ref.mean()) / ref.mean() < 0.04
     assert rel_rmse_trimmed(img, ref) < 0.2  # two independent 512-spp estimates: 0.14-0.15 in the oracle
     assert abs((rr + rs) - sum(orays)) / sum(orays) < 0.02
     # the guided estimator is not the unguided one (the reference's guided branch is biased)
