@@ -1111,9 +1111,13 @@ static void launch_bounce_t(const RenderParams& p, int qin, int bounces, int com
     else k_bounce<GUIDED, TRAIN, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact, cnt);
   }
 }
+static size_t lds_scene_limit() {
+  static const size_t kb = getenv("PT_LDS_SCENE_KB") ? (size_t)atoi(getenv("PT_LDS_SCENE_KB")) : 24u;
+  return kb * 1024u;
+}
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, QueueCounters cnt, const LaunchCfg& c) {
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
-  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= 24u * 1024u;
+  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
   size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
   const bool defer = p.defer_shadow && !p.acc2;
   if (defer) lds += (size_t)(c.threads / 64) * kDeferWords * sizeof(float);
@@ -1128,7 +1132,7 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, Que
 // them, and the dynamic LDS bytes of that launch.
 int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out) {
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
-  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= 24u * 1024u;
+  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
   size_t lds = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0);
   const bool defer = p.defer_shadow && !p.acc2;
   if (defer) lds += (size_t)(threads / 64) * kDeferWords * sizeof(float);
