@@ -156,6 +156,13 @@ PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
  * was measured 10 % slower than tracing in place). */
 PT_EXPORT void pt_set_defer_shadow(int on);
 PT_EXPORT int  pt_get_defer_shadow(void);
+/* Fused pipeline, renders with deferred shadow rays and a fixed sample count.  on (default, env PT_PERSIST=1): the
+ * whole render is one kernel launch; its waves take slots from a shared counter and a lane that has finished a slot
+ * takes the next one, so no path state goes through memory (1 % faster at 1024 samples a pixel, 3 % at 128).
+ * off: launch after launch, 32 bounces of every slot each.  The same paths either way; a slot's terms are added in
+ * a different order, so images agree to rounding. */
+PT_EXPORT void pt_set_one_launch(int on);
+PT_EXPORT int  pt_get_one_launch(void);
 
 /* Select the HIP device the next renderer is created on (default 0, or env PT_DEVICE). */
 PT_EXPORT void pt_set_device(int device);

@@ -9,7 +9,8 @@ namespace pt {
 
 // Device counters (uint32 words) shared by the wavefront kernels.
 // CNT_EXTEND / CNT_OCCLUDE: how much of the queue the waves of k_extend / k_occlude have taken so far (k_generate clears both)
-enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_SHADOW = 2, CNT_EXTEND = 3, CNT_OCCLUDE = 4, CNT_Q2 = 5, CNT_WORDS = 8 };
+// CNT_GRAB: how much of the queue the waves of the one-launch fused kernel have taken (zero when it starts)
+enum { CNT_Q0 = 0, CNT_Q1 = 1, CNT_SHADOW = 2, CNT_EXTEND = 3, CNT_OCCLUDE = 4, CNT_Q2 = 5, CNT_GRAB = 6, CNT_WORDS = 8 };
 
 // Everything a wavefront kernel needs, passed by value (lives in the kernarg segment).
 struct RenderParams {
@@ -20,6 +21,7 @@ struct RenderParams {
   int frame, max_depth;
   int sample_begin, sample_count;  // this call renders global samples [begin, begin+count) per pixel
   uint32_t npx;                    // width * height
+  uint32_t npx_inv, width_inv;     // ceil(2^32 / npx), ceil(2^32 / width): division by multiplication (decode_slot)
   int chunks, chunk_spp;           // the range is split into `chunks` slots per pixel of chunk_spp samples
   int round_limit;                 // > 0: no slot goes beyond this many samples yet (adaptive rounds)
   int strict;                      // 1: replay the reference's 4-sample launches literally
@@ -30,6 +32,8 @@ struct RenderParams {
   int shared_ranges;               // ... their waves take queue ranges from a shared counter (long rays) / hold one fixed share each
   int refill_lanes;                // staged traversal kernels: idle lanes that trigger taking new rays
   int defer_shadow;                // fused kernel: queue shadow rays per wave and trace them 64 at a time
+  int fresh_queue;                 // one-launch fused kernel: every queued slot is untouched (nothing to load)
+  int last_pass;                   // ... and none will run again (only totals are written back)
   // per-pixel path state, SoA of 16-byte words
   q4* st_o;   // origin.xyz, throughput.x
   q4* st_d;   // direction.xyz, throughput.y
@@ -83,6 +87,10 @@ struct QueueCounters {
 };
 inline int next_queue_counter(int c) { return c == CNT_Q0 ? CNT_Q1 : (c == CNT_Q1 ? CNT_Q2 : CNT_Q0); }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, QueueCounters cnt, const LaunchCfg& c);
+// Fused, the whole queue in one launch: every slot of queue qin (length in counters[cnt_in]) runs to its end; lanes take
+// queue entries from counters[CNT_GRAB], which must be zero at the start.  Launch with about as many blocks as stay resident.
+bool bounce_persist_usable(const RenderParams& p);
+void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c);
 
 // Adaptive sampling: active-pixel lists (ping-pong), the 3x3-dilated noise map and each pixel's own noise.
 struct AdaptiveBuffers {

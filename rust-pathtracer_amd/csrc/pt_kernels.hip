@@ -92,11 +92,18 @@ struct Slot {
   int begin;  // global index of the slot's first sample
   int count;  // samples this slot takes
 };
+// a / b for a, b < 2^31 with inv = ceil(2^32 / b) made on the host (0 for b = 1, whose constant does not fit): the
+// high half of a * inv is the quotient or one more
+__device__ __forceinline__ uint32_t fast_div(uint32_t a, uint32_t b, uint32_t inv) {
+  uint32_t q = __umulhi(a, inv);
+  if (q * b > a) --q;
+  return inv ? q : a;
+}
 __device__ __forceinline__ Slot decode_slot(const RenderParams& p, uint32_t slot) {
   Slot s;
-  const uint32_t chunk = p.chunks > 1 ? slot / p.npx : 0u;
+  const uint32_t chunk = p.chunks > 1 ? fast_div(slot, p.npx, p.npx_inv) : 0u;
   s.pixel = slot - chunk * p.npx;
-  s.y = (int)(s.pixel / (uint32_t)p.width);
+  s.y = (int)fast_div(s.pixel, (uint32_t)p.width, p.width_inv);
   s.x = (int)(s.pixel - (uint32_t)s.y * (uint32_t)p.width);
   s.begin = p.sample_begin + (int)chunk * p.chunk_spp;
   const int rem = p.sample_count - (int)chunk * p.chunk_spp;
@@ -695,7 +702,8 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
 // scalar registers, read back lane by lane inside the bounce loop.)
 constexpr uint32_t kDeferCap = 128;                       // queue entries per wave (fewer than 64 wait, up to 64 arrive)
 constexpr uint32_t kDeferFields = 12;                     // o.xyz d.xyz tmax origin contrib.xyz owner
-constexpr uint32_t kDeferWords = kDeferFields * kDeferCap + 3u * 64u;  // + per-lane accumulators
+constexpr uint32_t kDeferSet = 3u * 64u;                  // per-lane accumulators (x, y, z)
+constexpr uint32_t kDeferWords = kDeferFields * kDeferCap + kDeferSet;
 
 template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
 __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderParams p, int qin, int bounces, int compact,
@@ -854,6 +862,230 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
     }
     PT_TOC(t_epi, PT_T_EPILOGUE);
   }
+#ifdef PT_PROFILE
+  __syncthreads();
+  if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
+#endif
+  if (TRAIN) flush_train_count(p, captured);
+  for (int off = 32; off > 0; off >>= 1) {
+    rays_rad += __shfl_down(rays_rad, off);
+    rays_sh += __shfl_down(rays_sh, off);
+  }
+  if (lane == 0u) {
+    if (rays_rad) atomicAdd(&p.ray_counters[0], (unsigned long long)rays_rad);
+    if (rays_sh) atomicAdd(&p.ray_counters[1], (unsigned long long)rays_sh);
+  }
+}
+
+// ------------------------------------------------------------- fused, one launch per queue
+// The kernels above work through the slot queue launch after launch: a launch gives every slot a lane for a fixed
+// number of bounces, a slot that runs out of samples idles its lane until the launch ends (about 7 % of all lane
+// time: a slot lives for a dozen launches and ends, on average, half-way through one), and every launch ends with
+// its slowest wave.  Here the whole queue is one launch.  The grid is what the GPU keeps resident; every wave takes
+// queue entries in stretches of 64 from a counter all waves share and hands them to its lanes one by one: a lane
+// whose slot has taken its last sample writes the slot back and takes the next entry in the same iteration, so the
+// lanes stay busy until the queue is empty.  Nothing of a path touches memory between its slot's first and last
+// bounce, and there is no compaction: when the launch ends every slot of the queue has finished.
+//
+// Shadow rays go through the wave's queue in LDS as in k_bounce_defer.  The lane keeps two accumulators in LDS
+// for as long as its slot lives: the sum of the slot's finished samples, in sample order, and the credits of its
+// unoccluded shadow rays, in queue order; their sum goes to the slot's total when it retires, which it does only
+// after its last queued ray has been traced (two counters per wave -- entries queued, entries traced -- and the
+// position of the lane's last entry tell when; the wait is two iterations out of hundreds).  A slot's result does
+// not depend on the lane or the wave that carried it, or on what shared the wave: renders stay reproducible bit for
+// bit although slots reach lanes in a different order every time.
+//
+// What it costs: a lane refills alone, so the hundred-odd instructions that write one slot back and set up the next
+// run at one lane in 64 where a launch of k_bounce_defer does them for 64 slots at once (+3.3 % vector instructions
+// measured, against 6.3 % fewer loop iterations).  Renders whose slots live long gain little (1 % at 1024 samples a
+// pixel), short ones more (3.4 % at 128: their launches are all head and tail); slots of an adaptive round's 8 or 16
+// samples would refill every few iterations, so adaptive renders stay with k_bounce.
+//
+// RenderParams::fresh_queue: every slot of the queue is untouched (a fixed-count render's only launch): nothing is
+// loaded for it.  RenderParams::last_pass: no slot will run again after this launch: only its totals are written.
+constexpr uint32_t kPersistGrab = 64;  // queue entries a wave takes from the shared counter at a time
+// per wave: the shadow queue (owner and origin share a word: 11 fields), credits, finished-sample sums, last-entry marks
+constexpr uint32_t kPersistWords = (kDeferFields - 1u) * kDeferCap + 2u * kDeferSet + 64u;
+constexpr uint32_t kPersistOriginBits = 26;  // a shadow ray's origin primitive (+1) beside its owner lane in one word
+
+template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
+__global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderParams p, int qin, int cnt_in) {
+  const uint32_t n = p.counters[cnt_in];
+  const uint32_t* q_in = p.queue[qin];
+  LdsStack st = lds_stack();
+  SceneView sc = p.scene;
+  u4* lds_free = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
+  if (LDS_SCENE) {
+    lds_free = stage_scene(p, lds_free, sc);
+    __builtin_assume(sc.wide != nullptr);
+  } else {
+    sc.wide = nullptr;
+  }
+#ifdef PT_PROFILE
+  if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
+  __syncthreads();
+#endif
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  float* dq = reinterpret_cast<float*>(lds_free) + (size_t)(threadIdx.x >> 6) * kPersistWords;  // this wave's queue
+  float* late = dq + (kDeferFields - 1u) * kDeferCap;                       // [3][64]: credits of the lane's slot
+  float* done_sum = late + kDeferSet;                                       // [3][64]: its finished samples
+  uint32_t* last_entry = reinterpret_cast<uint32_t*>(done_sum + kDeferSet); // [64]: 1 + position of its last queued ray
+  const ShadeParams sp = shade_params(p);
+  uint32_t rays_rad = 0, rays_sh = 0, captured = 0;
+  const bool fresh = p.fresh_queue != 0, last_pass = p.last_pass != 0;
+
+  auto trace_deferred = [&](uint32_t e) {
+    const f3 o = mk3(dq[0 * kDeferCap + e], dq[1 * kDeferCap + e], dq[2 * kDeferCap + e]);
+    const f3 d = mk3(dq[3 * kDeferCap + e], dq[4 * kDeferCap + e], dq[5 * kDeferCap + e]);
+    const float tmax = dq[6 * kDeferCap + e];
+    const uint32_t word = f2u(dq[7 * kDeferCap + e]);
+    rays_sh++;
+    PT_PROF(PF_SHADOW);
+    PT_TIC(t_sh);
+    const Hit h = trace_ray(sc, o, d, 0.0f, tmax, true, st, p.stack_depth, word & ((1u << kPersistOriginBits) - 1u));
+    if (h.prim < 0) {
+      const uint32_t owner = word >> kPersistOriginBits;
+      atomicAdd(&late[owner], dq[8 * kDeferCap + e]);
+      atomicAdd(&late[64u + owner], dq[9 * kDeferCap + e]);
+      atomicAdd(&late[128u + owner], dq[10 * kDeferCap + e]);
+    }
+    PT_TOC(t_sh, PT_T_SHADOW);
+  };
+
+  // the lane's slot
+  bool has_slot = false, retiring = false;
+  uint32_t pixel = 0;
+  int local = 0;
+  PathState ps;
+  ps.o = ps.d = ps.T = ps.sum = mk3(0.0f);
+  ps.seed = 0;
+  ps.prev_pdf = 0.0f;
+  ps.flags = 0u;
+  ps.origin = 0u;
+  Slot sl = decode_slot(p, 0u);
+  RandCtx rc = make_rand_ctx(0, 0, 0, p.frame);
+  late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
+  done_sum[lane] = 0.0f; done_sum[64u + lane] = 0.0f; done_sum[128u + lane] = 0.0f;
+  last_entry[lane] = 0u;
+  // the same on every lane of the wave
+  uint32_t head = 0, waiting = 0, queued_total = 0, traced_total = 0;  // the LDS queue
+  uint32_t grab_pos = 0, grab_end = 0;                                  // the stretch of the slot queue the wave holds
+  bool more = n > 0u;                                                   // the shared counter has not run past the queue yet
+  PT_TIC(t_loop);
+  for (;;) {
+    // a slot whose last sample is folded and whose queued rays are all traced goes back to memory
+    if (has_slot && retiring && traced_total >= last_entry[lane]) {
+      // total = what the slot held before + its samples of this launch in order + their credits in queue order
+      f3 v = mk3(done_sum[lane], done_sum[64u + lane], done_sum[128u + lane]);
+      v += mk3(late[lane], late[64u + lane], late[128u + lane]);
+      q4 acc = q4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (!fresh) acc = p.acc[pixel];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z;
+      p.acc[pixel] = acc;
+      late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
+      done_sum[lane] = 0.0f; done_sum[64u + lane] = 0.0f; done_sum[128u + lane] = 0.0f;
+      last_entry[lane] = 0u;
+      if (!last_pass) store_state(p, pixel, ps);
+      p.started[pixel] = local;
+      has_slot = false;
+      retiring = false;
+    }
+    // lanes without a slot take the next queue entries
+    {
+      unsigned long long need = __ballot(!has_slot);
+      while (need != 0ull && (grab_pos < grab_end || more)) {
+        if (grab_pos == grab_end) {  // a new stretch from the counter all waves share
+          uint32_t b = 0u;
+          if (lane == 0u) b = atomicAdd(&p.counters[CNT_GRAB], kPersistGrab);
+          b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+          if (b >= n) { more = false; break; }
+          grab_pos = b;
+          grab_end = b + kPersistGrab < n ? b + kPersistGrab : n;
+        }
+        const uint32_t n_need = (uint32_t)__popcll(need), room = grab_end - grab_pos;
+        const uint32_t take = n_need < room ? n_need : room;
+        const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
+        if (!has_slot && rank < take) {
+          pixel = q_in[grab_pos + rank];
+          if (fresh) {  // an untouched slot: no samples started, no path under way
+            ps.flags = 0u;
+            ps.seed = 0;
+            local = 0;
+          } else {
+            ps = load_state(p, pixel);
+            local = p.started[pixel];
+          }
+          sl = decode_slot(p, pixel);
+          rc = make_rand_ctx(sl.x, sl.y, 0, p.frame);  // the pixel's noise shift: once per slot
+          has_slot = true;
+          // nothing to do for this slot (a queue may list slots that have finished): it retires at once
+          retiring = !(ps.flags & (kAlive | kFoldPending)) && local >= sl.count;
+        }
+        grab_pos += take;
+        need = __ballot(!has_slot);
+      }
+    }
+    const unsigned long long running = __ballot(has_slot && !retiring);
+    if (running == 0ull && __ballot(has_slot) == 0ull) break;  // the queue is empty and every slot is back in memory
+    const bool active = has_slot && !retiring;
+    ShadowRay sr;
+    sr.valid = false;
+    if (active) { PT_PROF(PF_BOUNCE); }
+    PT_TIC(t_regen);
+    if (active && !(ps.flags & kAlive)) {
+      PT_PROF(PF_REGEN);
+      if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's sum
+        done_sum[lane] += ps.sum.x; done_sum[64u + lane] += ps.sum.y; done_sum[128u + lane] += ps.sum.z;
+        ps.flags &= ~kFoldPending;
+      }
+      if (local >= sl.count) {
+        retiring = true;
+      } else {
+        generate_path(p.cam, rc, hash_sample_index(p, sl, local), p.width, p.height, start_seed(p, sl, local, ps.seed), ps);
+        local++;
+      }
+    }
+    PT_TOC(t_regen, PT_T_REGEN);
+    if (active && !retiring) {
+      rc.s = hash_sample_index(p, sl, local - 1);
+      PT_TIC(t_trace);
+      const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth, ps.origin);
+      PT_TOC(t_trace, PT_T_TRACE);
+      rays_rad++;
+      TrainVertex tv;
+      PT_TIC(t_shade);
+      shade_hit<GUIDED, TRAIN>(sc, p.guide, sp, rc, ps, h, sr, tv);
+      if (TRAIN) capture_train(p, tv, ps.seed, pixel, captured);
+      PT_TOC(t_shade, PT_T_SHADE);
+    }
+    {
+      PT_TIC(t_enq);
+      const unsigned long long made = __ballot(sr.valid);
+      if (sr.valid) {
+        const uint32_t rank = (uint32_t)__popcll(made & lanes_below);
+        const uint32_t e = (head + waiting + rank) & (kDeferCap - 1u);
+        dq[0 * kDeferCap + e] = sr.o.x; dq[1 * kDeferCap + e] = sr.o.y; dq[2 * kDeferCap + e] = sr.o.z;
+        dq[3 * kDeferCap + e] = sr.d.x; dq[4 * kDeferCap + e] = sr.d.y; dq[5 * kDeferCap + e] = sr.d.z;
+        dq[6 * kDeferCap + e] = sr.tmax;
+        dq[7 * kDeferCap + e] = u2f(sr.origin | (lane << kPersistOriginBits));
+        dq[8 * kDeferCap + e] = sr.contrib.x; dq[9 * kDeferCap + e] = sr.contrib.y; dq[10 * kDeferCap + e] = sr.contrib.z;
+        last_entry[lane] = queued_total + rank + 1u;
+      }
+      waiting += (uint32_t)__popcll(made);
+      queued_total += (uint32_t)__popcll(made);
+      PT_TOC(t_enq, PT_T_ENQUEUE);
+      // 64 at a time; what is left, at whatever occupancy, once only lanes that wait for it remain
+      if (waiting >= 64u || (waiting > 0u && __ballot(has_slot && !retiring) == 0ull)) {
+        const uint32_t cnt = waiting < 64u ? waiting : 64u;
+        if (lane < cnt) trace_deferred((head + lane) & (kDeferCap - 1u));
+        head = (head + cnt) & (kDeferCap - 1u);
+        waiting -= cnt;
+        traced_total += cnt;
+      }
+    }
+  }
+  PT_TOC(t_loop, PT_T_LOOP);
 #ifdef PT_PROFILE
   __syncthreads();
   if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
@@ -1126,6 +1358,28 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, Que
   else if (g) launch_bounce_t<true, false>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
   else if (t) launch_bounce_t<false, true>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
   else launch_bounce_t<false, false>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
+  PT_KCHECK();
+}
+template <bool GUIDED, bool TRAIN>
+static void launch_persist_t(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c, bool lds_scene, size_t lds) {
+  if (lds_scene) k_bounce_persist<GUIDED, TRAIN, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+  else k_bounce_persist<GUIDED, TRAIN, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+}
+// k_bounce_persist carries what k_bounce_defer carries: renders with deferred shadow rays and no per-sample sums
+// (a shadow ray's origin primitive shares a word with its owner lane, which bounds the triangle count).
+bool bounce_persist_usable(const RenderParams& p) {
+  return p.defer_shadow && !p.acc2 && p.scene.num_tris < (1u << kPersistOriginBits) - 1u;
+}
+// The whole of queue qin (its length in counters[cnt_in]) in one launch; counters[CNT_GRAB] must be zero.
+void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c) {
+  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
+  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
+  const size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0) + (size_t)(c.threads / 64) * kPersistWords * sizeof(float);
+  const bool g = p.guiding != 0, t = p.train != nullptr;
+  if (g && t) launch_persist_t<true, true>(p, qin, cnt_in, c, lds_scene, lds);
+  else if (g) launch_persist_t<true, false>(p, qin, cnt_in, c, lds_scene, lds);
+  else if (t) launch_persist_t<false, true>(p, qin, cnt_in, c, lds_scene, lds);
+  else launch_persist_t<false, false>(p, qin, cnt_in, c, lds_scene, lds);
   PT_KCHECK();
 }
 // Resident blocks per CU of the fused kernel launch_bounce would pick for these parameters, as the runtime counts

@@ -47,6 +47,7 @@ KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
 int g_fused_bounces = 32;  // bounces per fused launch (1080p, 1024 spp: 16 389.7 ms, 24 382.0, 32 382.7, 48 382.2, 64 388.4)
 int g_defer_shadow = getenv("PT_DEFER_SHADOW") ? atoi(getenv("PT_DEFER_SHADOW")) : 1;
+int g_one_launch = getenv("PT_PERSIST") ? (atoi(getenv("PT_PERSIST")) != 0) : 1;
 int g_adaptive_round = getenv("PT_ADAPTIVE_ROUND") ? atoi(getenv("PT_ADAPTIVE_ROUND")) : -32;
 int g_adaptive_chunks = getenv("PT_ADAPTIVE_CHUNKS") ? atoi(getenv("PT_ADAPTIVE_CHUNKS")) : 0;  // 0: as many as fit
 constexpr size_t kTargetSlots = 8u << 20;       // path slots a renderer starts with (pixels x chunks); adaptive renders stay within them
@@ -477,6 +478,9 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   p.sample_count = sample_count;
   p.strict = strict ? 1 : 0;
   p.npx = (uint32_t)((size_t)s.width * (size_t)s.height);
+  auto inv32 = [](uint32_t b) { return b > 1u ? (uint32_t)(((1ull << 32) + b - 1u) / b) : 0u; };  // 0: divide by one
+  p.npx_inv = inv32(p.npx);
+  p.width_inv = inv32((uint32_t)s.width);
   // chunks: strict mode replays one stream per pixel; converge mode splits the range (chunks_for_render)
   p.chunks = std::max(grow ? chunks_for_render(s, sample_count, strict) : 1, 1);
   p.chunk_spp = (sample_count + p.chunks - 1) / p.chunks;
@@ -518,7 +522,7 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
 struct RenderLoop {
   State& s;
   RenderParams p;
-  LaunchCfg cfg, cfg_fused;
+  LaunchCfg cfg, cfg_fused, cfg_persist;
   bool fused;
   bool tail_fused = false;
   uint64_t iter = 0;
@@ -537,6 +541,10 @@ struct RenderLoop {
     cfg.stream = s.stream;
     cfg_fused = cfg;
     cfg_fused.blocks = blocks_for(32);
+    // the one-launch kernel: as many blocks as stay resident (4 per CU at 128 registers and under 40 KB of LDS each)
+    static const int persist_bpc = getenv("PT_PERSIST_BLOCKS_PER_CU") ? std::max(atoi(getenv("PT_PERSIST_BLOCKS_PER_CU")), 1) : 4;
+    cfg_persist = cfg;
+    cfg_persist.blocks = std::max((int)std::min<size_t>((slots + 255) / 256, (size_t)s.num_cus * (size_t)persist_bpc), 1);
     // Small scenes are instruction-bound: keep paths in registers (fused).  Scenes whose BVH lives in
     // HBM are latency-bound: the lean staged kernels run at twice the occupancy and win.
     const int chosen = pipeline();
@@ -573,7 +581,10 @@ struct RenderLoop {
     init[CNT_Q0] = n;
     HIP_CHECK(hipMemcpyAsync(s.counters, init, CNT_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
     static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
-    bool use_fused = fused;
+    // Renders without per-sample sums and with deferred shadow rays take the whole queue in one launch;
+    // PT_PERSIST=0: they too go launch after launch (32 bounces of every slot per launch, queue compacted).
+    const bool persist = g_one_launch != 0 && bounce_persist_usable(p);
+    bool use_fused = fused, done = false;
     int qin = 0, slot = 0;
     int cin = CNT_Q0;      // the counter that holds the length of queue[qin] (the staged kernels keep it in counters[qin])
     int live[2] = {0, 0};  // per read-back slot: the counter that held the number of live slots when it was taken
@@ -582,6 +593,14 @@ struct RenderLoop {
       const int iters_per_batch = use_fused ? 8 : 16;
       for (int b = 0; b < iters_per_batch; ++b, ++iter) {
         const bool timed = !s.borrowed && g_timing_every > 0 && (iter % (uint64_t)g_timing_every) == 0;
+        if (use_fused && persist) {
+          // One launch takes the whole queue to its end (k_bounce_persist): nothing to read back afterwards.
+          HIP_CHECK(hipMemsetAsync(s.counters + CNT_GRAB, 0, sizeof(uint32_t), s.stream));
+          Timer t(s, PT_K_BOUNCE, timed, 0);
+          launch_bounce_persist(p, qin, cin, cfg_persist);
+          done = true;
+          break;
+        }
         if (use_fused) {
           // The slot queue is compacted by every launch (PT_COMPACT_EVERY=n: by every n-th, a divisor of the batch
           // length): a finished slot left in the queue costs more than its state read -- it idles a lane of a wave
@@ -606,6 +625,7 @@ struct RenderLoop {
         qin ^= 1;
         cin = qin;  // CNT_Q0 / CNT_Q1; the other one has been cleared by k_occlude, CNT_Q2 is untouched
       }
+      if (done) break;
       // Only the counter of the queue the next launch reads says how many slots are live: the others
       // hold earlier lengths until a later launch clears them.
       if (s.borrowed) {  // no pinned memory and no events: a blocking copy after every batch
@@ -653,6 +673,10 @@ struct RenderLoop {
 
 void render_core(State& s, const RenderParams& params) {
   RenderLoop loop(s, params);
+  // a fixed-count render that runs fused from its first launch: every slot is untouched when its one launch takes it,
+  // and none runs again
+  loop.p.fresh_queue = loop.fused ? 1 : 0;
+  loop.p.last_pass = 1;
   s.last_chunks = loop.p.chunks;
   s.adaptive_rounds = 0;
   const size_t slots = (size_t)loop.p.npx * (size_t)loop.p.chunks;
@@ -1491,6 +1515,8 @@ void pt_reset_kernel_stats(void) {
 }
 void pt_set_defer_shadow(int on) { g_defer_shadow = on ? 1 : 0; }
 int pt_get_defer_shadow(void) { return g_defer_shadow; }
+void pt_set_one_launch(int on) { g_one_launch = on ? 1 : 0; }
+int pt_get_one_launch(void) { return g_one_launch; }
 void pt_set_adaptive_round(int samples) { g_adaptive_round = samples != 0 ? samples : -32; }
 int pt_get_adaptive_round(void) { return g_adaptive_round; }
 void pt_set_adaptive_chunks(int chunks) { g_adaptive_chunks = chunks > 0 ? chunks : 0; }

@@ -111,6 +111,8 @@ SIGNATURES = {
     "pt_dbg_profile_counters": (C.c_int, [C.POINTER(C.c_uint64)]),
     "pt_dbg_fused_occupancy": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "pt_set_defer_shadow": (None, [C.c_int]),
+    "pt_set_one_launch": (None, [C.c_int]),
+    "pt_get_one_launch": (C.c_int, []),
     "pt_get_defer_shadow": (C.c_int, []),
     "pt_set_adaptive_round": (None, [C.c_int]),
     "pt_get_adaptive_round": (C.c_int, []),
