@@ -14,6 +14,10 @@
 #define PT_GUIDE_EARLY_BATCH 1
 #endif
 
+#ifndef PT_SHARED_DISK
+#define PT_SHARED_DISK 1
+#endif
+
 namespace pt {
 
 // Register image of one path.  In HBM it is four 16-byte SoA streams:
@@ -87,18 +91,16 @@ PT_HD f3 reflect(f3 i, f3 n) { return i - n * (2.0f * dot(i, n)); }
 // renormalising a vector that is unit by construction (a unit vector in an orthonormal frame, the mirror image of
 // one) changes its last bit at most: left out
 PT_HD f3 unit_by_construction(f3 v) { return v; }
-// g1v: the Smith term of the view direction, which the caller has already (it depends on N.V and alpha only)
-PT_HD void sample_ggx_vndf(float ux, float uy, float alpha, f3 N, f3 V, f3& L, f3& H, float& pdf, float g1v = -1.0f) {
-  f3 T, B;
-  make_onb(N, T, B);
+// g1v: the Smith term of the view direction, which the caller has already (it depends on N.V and alpha only).
+// (T, B): the frame make_onb gives for N; (t1, t2): the point of the unit disk the two random numbers map to,
+// sqrt(ux) * (cos, sin)(2 pi uy) -- the caller's diffuse lobe needs the same frame and the same kind of point,
+// so both are made once, before the lobes part ways.
+PT_HD void sample_ggx_vndf_disk(float t1, float t2, float alpha, f3 N, f3 T, f3 B, f3 V, f3& L, f3& H, float& pdf, float g1v) {
   const f3 Vlocal = mk3(dot(V, T), dot(V, B), dot(V, N));
   const f3 Vh = normalize_chk(mk3(alpha * Vlocal.x, alpha * Vlocal.y, Vlocal.z));
   const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
   const f3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * rsqrt(lensq) : mk3(1.0f, 0.0f, 0.0f);
   const f3 T2 = cross(Vh, T1);
-  const float r = fsqrt(ux);
-  const float t1 = r * cos2pi(uy);
-  float t2 = r * sin2pi(uy);
   const float s = 0.5f * (1.0f + Vh.z);
   t2 = (1.0f - s) * fsqrt(fmaxf(0.0f, 1.0f - t1 * t1)) + s * t2;
   const f3 Nh = T1 * t1 + T2 * t2 + Vh * fsqrt(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
@@ -113,6 +115,12 @@ PT_HD void sample_ggx_vndf(float ux, float uy, float alpha, f3 N, f3 V, f3& L, f
   const float D = alpha2 * rcp(kPi * denom * denom);
   const float G1V = g1v >= 0.0f ? g1v : 2.0f * NoV * rcp(NoV + fsqrt(alpha2 + (1.0f - alpha2) * NoV * NoV));
   pdf = (D * NoH * G1V) * rcp(4.0f * fmaxf(VoH, 1e-6f));
+}
+PT_HD void sample_ggx_vndf(float ux, float uy, float alpha, f3 N, f3 V, f3& L, f3& H, float& pdf, float g1v = -1.0f) {
+  f3 T, B;
+  make_onb(N, T, B);
+  const float r = fsqrt(ux);
+  sample_ggx_vndf_disk(r * cos2pi(uy), r * sin2pi(uy), alpha, N, T, B, V, L, H, pdf, g1v);
 }
 
 // optix_device.cu:660-672 (== 468-480).  Returns false when the path ends here.
@@ -313,14 +321,36 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
     radiance = emission;
 
     const float choose = next_rand(ps, rc);
-    if (choose < spec_prob) {
+    const bool take_spec = choose < spec_prob;
+    // Either lobe draws two more numbers, maps them to a point of the unit disk -- radius sqrt(one), angle 2 pi
+    // times the other: the specular lobe's first number is its radius, the diffuse lobe's first its angle -- and
+    // needs make_onb's frame of the normal.  Without a guiding field (whose diffuse lobe draws differently) this is
+    // done here for both, so the few lanes of a wave that take the specular lobe run that much less on their own.
+    const bool shared_disk = PT_SHARED_DISK && !(GUIDED && sp.guiding);
+    float disk_x = 0.0f, disk_y = 0.0f, disk_r2 = 0.0f;
+    f3 onb_t = mk3(0.0f), onb_b = mk3(0.0f);
+    if (shared_disk) {
+      const float ua = next_rand(ps, rc);
+      const float ub = next_rand(ps, rc);
+      disk_r2 = take_spec ? ua : ub;
+      const float ang = take_spec ? ub : ua;
+      const float r = fsqrt(disk_r2);
+      disk_x = r * cos2pi(ang);
+      disk_y = r * sin2pi(ang);
+      make_onb(Ng, onb_t, onb_b);
+    }
+    if (take_spec) {
       PT_PROF(PF_SPEC);
       // optix_device.cu:564-589
-      const float ux = next_rand(ps, rc);
-      const float uy = next_rand(ps, rc);
       f3 newDir, H;
       float pdf;
-      sample_ggx_vndf(ux, uy, alpha, Ng, V, newDir, H, pdf, G1V_shared);
+      if (shared_disk) {
+        sample_ggx_vndf_disk(disk_x, disk_y, alpha, Ng, onb_t, onb_b, V, newDir, H, pdf, G1V_shared);
+      } else {
+        const float ux = next_rand(ps, rc);
+        const float uy = next_rand(ps, rc);
+        sample_ggx_vndf(ux, uy, alpha, Ng, V, newDir, H, pdf, G1V_shared);
+      }
       const float NoL = fmaxf(dot(Ng, newDir), 0.0f);
       const float VoH = fmaxf(dot(V, H), 0.0f);
       const float NoH = fmaxf(dot(Ng, H), 0.0f);
@@ -381,13 +411,20 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
         }
       }
       if (!used_guiding) {
-        const float r1 = next_rand(ps, rc);
-        const float r2 = next_rand(ps, rc);
-        cosTheta = fsqrt(1.0f - r2);
-        const float sinTheta = fsqrt(r2);
-        const f3 local = mk3(cos2pi(r1) * sinTheta, sin2pi(r1) * sinTheta, cosTheta);
-        f3 tangent, bitangent;
-        make_onb(Ng, tangent, bitangent);
+        f3 local, tangent, bitangent;
+        if (shared_disk) {
+          cosTheta = fsqrt(1.0f - disk_r2);
+          local = mk3(disk_x, disk_y, cosTheta);
+          tangent = onb_t;
+          bitangent = onb_b;
+        } else {
+          const float r1 = next_rand(ps, rc);
+          const float r2 = next_rand(ps, rc);
+          cosTheta = fsqrt(1.0f - r2);
+          const float sinTheta = fsqrt(r2);
+          local = mk3(cos2pi(r1) * sinTheta, sin2pi(r1) * sinTheta, cosTheta);
+          make_onb(Ng, tangent, bitangent);
+        }
         newDir = unit_by_construction(tangent * local.x + bitangent * local.y + Ng * local.z);
         p_bsdf = cosTheta * kInvPi;
         // (the reference also evaluates the mixture pdf of this direction, optix_device.cu:647, and never uses it)
