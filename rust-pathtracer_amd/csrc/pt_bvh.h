@@ -160,6 +160,12 @@ PT_HD int fast_triangle(const q4& q0, const q4& q1, const q4& q2, const q4& q3, 
 // The undecided case of fast_triangle: the watertight test on the original vertices of the item's
 // triangle(s) decides.  Testing a triangle the point is not near costs time only.
 PT_HD bool watertight_item(const SceneView& sc, const q4& q1, const q4& q2, const q4& q3, f3 o, f3 d, float tmin, Hit& hit) {
+#if PT_ON_DEVICE
+  // This runs for one ray in thousands.  Its per-ray constants depend on the direction alone, and the compiler, left
+  // to itself, computes them ahead of the traversal loop for every ray (some 60 selects, a dozen registers held
+  // through the loop); the empty statement ties the direction to this place.
+  asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
+#endif
   const RayShear rs = make_shear(d);
   const int prim = (int)f2u(q1.w);
   const q4* rec = reinterpret_cast<const q4*>(sc.shade + prim);

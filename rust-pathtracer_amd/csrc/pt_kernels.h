@@ -117,7 +117,7 @@ void launch_unpack_stats(const float* stats, q4* acc, q4* acc2, int* count, uint
 void launch_add_stats(float* own, const float* peer, size_t n, hipStream_t s);
 void launch_stats_mean(const float* stats, float* out_rgb, uint32_t npx, hipStream_t s);
 // resident blocks per CU of the fused kernel launch_bounce picks for p (unguided, no training ring), and its LDS bytes
-int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out);
+int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out, bool one_launch);
 // profiling build (-DPT_PROFILE) only: section counters, (waves, lanes) pairs; returns the number of sections
 int read_profile_counters(unsigned long long* out64);
 void launch_iota(uint32_t* dst, uint32_t n, hipStream_t s);

@@ -895,6 +895,16 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
 // not depend on the lane or the wave that carried it, or on what shared the wave: renders stay reproducible bit for
 // bit although slots reach lanes in a different order every time.
 //
+// Item tests shared across the wave were built on this kernel and taken out again.  A lane tested its ray's first
+// candidate itself; the candidates left over in the wave went to a list in LDS and were tested 64 pairs at a time by
+// whichever lane, the ray read from its owner's registers (ds_bpermute), the closest hit handed back through a
+// 64-bit LDS minimum of (distance, testing lane).  It did what it was meant to -- 2.0 rounds of item tests per
+// closest-hit query instead of 4.2, 58 % of lanes active instead of 54 % -- and was 13 % slower (412.8 against
+// 366.0 ms): building the list, eleven lane reads and the key traffic cost more instructions than the two rounds of
+// a 55-instruction test they replaced (+3.7 % vector, +9 % scalar, +10 % LDS instructions, 23 spilled registers
+// against 7), and 27 of 10.8 G rays found another hit (a candidate is rejected against the closest hit before the
+// node's items, not the closest so far, which matters where two surfaces meet within the rounding of one test).
+//
 // What it costs: a lane refills alone, so the hundred-odd instructions that write one slot back and set up the next
 // run at one lane in 64 where a launch of k_bounce_defer does them for 64 slots at once (+3.3 % vector instructions
 // measured, against 6.3 % fewer loop iterations).  Renders whose slots live long gain little (1 % at 1024 samples a
@@ -1370,11 +1380,16 @@ static void launch_persist_t(const RenderParams& p, int qin, int cnt_in, const L
 bool bounce_persist_usable(const RenderParams& p) {
   return p.defer_shadow && !p.acc2 && p.scene.num_tris < (1u << kPersistOriginBits) - 1u;
 }
+static size_t persist_lds_bytes(const RenderParams& p, int threads, bool& lds_scene) {
+  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
+  lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
+  return (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) +
+         (size_t)(threads / 64) * kPersistWords * sizeof(float);
+}
 // The whole of queue qin (its length in counters[cnt_in]) in one launch; counters[CNT_GRAB] must be zero.
 void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c) {
-  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
-  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
-  const size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0) + (size_t)(c.threads / 64) * kPersistWords * sizeof(float);
+  bool lds_scene;
+  const size_t lds = persist_lds_bytes(p, c.threads, lds_scene);
   const bool g = p.guiding != 0, t = p.train != nullptr;
   if (g && t) launch_persist_t<true, true>(p, qin, cnt_in, c, lds_scene, lds);
   else if (g) launch_persist_t<true, false>(p, qin, cnt_in, c, lds_scene, lds);
@@ -1384,7 +1399,16 @@ void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const Lau
 }
 // Resident blocks per CU of the fused kernel launch_bounce would pick for these parameters, as the runtime counts
 // them, and the dynamic LDS bytes of that launch.
-int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out) {
+int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out, bool one_launch) {
+  if (one_launch && bounce_persist_usable(p)) {
+    bool lds_scene;
+    const size_t lds = persist_lds_bytes(p, threads, lds_scene);
+    if (lds_out) *lds_out = lds;
+    int n = 0;
+    const hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, true>, threads, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, false>, threads, lds);
+    return e == hipSuccess ? n : -1;
+  }
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
   const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
   size_t lds = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0);

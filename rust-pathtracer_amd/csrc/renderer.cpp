@@ -1556,7 +1556,7 @@ int pt_dbg_fused_occupancy(int adaptive, unsigned long long* lds_bytes) {
   RenderParams p = make_params(s, 0, 64, 32, 1, false, false);
   if (adaptive) p.acc2 = reinterpret_cast<q4*>(s.st_o);  // only tested for being set
   size_t lds = 0;
-  const int n = bounce_occupancy(p, 256, &lds);
+  const int n = bounce_occupancy(p, 256, &lds, g_one_launch != 0);
   if (lds_bytes) *lds_bytes = lds;
   return n;
 }
