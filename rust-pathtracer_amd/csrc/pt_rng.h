@@ -47,7 +47,12 @@ PT_HD void blue_noise(int x, int y, int s, int frame, float& u, float& v) {
 }
 
 // optix_device.cu:187-190: triangle-filter warp to [-1,1]
-PT_HD float sample_tri(float u) { return (u < 0.5f) ? fsqrt(2.0f * u) - 1.0f : 1.0f - fsqrt(2.0f * (1.0f - u)); }
+// (one square root for both halves: the operand is chosen first)
+PT_HD float sample_tri(float u) {
+  const bool low = u < 0.5f;
+  const float r = fsqrt(2.0f * (low ? u : 1.0f - u));
+  return low ? r - 1.0f : 1.0f - r;
+}
 
 // optix_device.cu:945-948
 PT_HD uint64_t pixel_seed(int frame, uint32_t dst) {

@@ -204,6 +204,13 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
     tv.T_in = ps.T;
   }
 
+  // Both kinds of surface start the same way: the reflectance at normal incidence, and one random number (the
+  // dielectric's choice between reflection and refraction, the first coordinate of the opaque surface's light
+  // sample).  Done once, ahead of the branch: the few lanes of a wave on glass then run that much less alone.
+  float f0 = (IOR - 1.0f) * rcp(IOR + 1.0f);
+  f0 = f0 * f0;
+  const float u_first = next_rand(ps, rc);
+
   f3 radiance;
   if (Transmission > 0.0f) {
     PT_PROF(PF_GLASS);
@@ -212,10 +219,8 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
     const f3 N = entering ? Ng : -Ng;
     const float eta = entering ? rcp(IOR) : IOR;
     const float cosi = fmaxf(dot(-N, dir), 0.0f);
-    float f0 = (IOR - 1.0f) * rcp(IOR + 1.0f);
-    f0 = f0 * f0;
     const float Fr = f0 + (1.0f - f0) * pow5(1.0f - cosi);
-    bool do_reflect = next_rand(ps, rc) < Fr;
+    bool do_reflect = u_first < Fr;
     f3 Tdir = mk3(0.f);
     if (!do_reflect) {
       // optix_device.cu:266-273
@@ -241,8 +246,6 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
   } else {
     PT_PROF(PF_OPAQUE);
     // optix_device.cu:484-492
-    float f0 = (IOR - 1.0f) * rcp(IOR + 1.0f);
-    f0 = f0 * f0;
     const f3 V = -dir;
     const float NoV = fmaxf(dot(Ng, V), 0.0f);
     const float F = schlick(NoV, f0);
@@ -270,7 +273,7 @@ PT_HD void shade_surface(const SceneView& sc, const GuideView& gv, const ShadePa
     // optix_device.cu:495-548: next-event estimation towards the rectangle light
     f3 Lo = mk3(0.0f);
     {
-      const float u = (next_rand(ps, rc) * 2.0f - 1.0f) * sc.light_half[0];
+      const float u = (u_first * 2.0f - 1.0f) * sc.light_half[0];
       const float v = (next_rand(ps, rc) * 2.0f - 1.0f) * sc.light_half[1];
       const f3 lp = mk3(sc.light_pos[0] + u, sc.light_pos[1] + v, sc.light_pos[2]);
       const f3 L = lp - P;
