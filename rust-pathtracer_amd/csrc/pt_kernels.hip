@@ -598,6 +598,25 @@ __device__ __forceinline__ u4* stage_scene(const RenderParams& p, u4* dst, Scene
   return dst + staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
 }
 
+// The camera -- 12 numbers a lane needs once per sample -- waits in LDS, at the end of the block's allocation, rather
+// than in scalar registers, of which the bounce loop has too few: the compiler parks what does not fit in a vector
+// register and fetches it back lane by lane (v_readlane) inside the loop.  With the camera out of the way the
+// one-launch kernel spills 10 scalar registers instead of 33 and runs 1.4 % faster.
+constexpr uint32_t kCamLdsBytes = 64;
+__device__ __forceinline__ const float* stage_camera(const RenderParams& p, void* at) {  // whole block; ends with a barrier
+  float* c = reinterpret_cast<float*>(at);
+  if (threadIdx.x < 12u) c[threadIdx.x] = reinterpret_cast<const float*>(&p.cam)[threadIdx.x];
+  __syncthreads();
+  return c;
+}
+__device__ __forceinline__ CameraView lds_camera(const float* c) {
+  CameraView cam;
+  for (int k = 0; k < 3; ++k) {
+    cam.eye[k] = c[k]; cam.u[k] = c[3 + k]; cam.v[k] = c[6 + k]; cam.w[k] = c[9 + k];
+  }
+  return cam;
+}
+
 template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
 __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p, int qin, int bounces, int compact, QueueCounters cnt) {
   const uint32_t n = p.counters[cnt.in];
@@ -605,13 +624,14 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
   uint32_t* q_out = p.queue[qin ^ 1];
   LdsStack st = lds_stack();
   SceneView sc = p.scene;
+  u4* lds_free = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
   if (LDS_SCENE) {
-    u4* dst = reinterpret_cast<u4*>(g_lds_stack + (size_t)blockDim.x * (size_t)p.stack_depth);
-    stage_scene(p, dst, sc);
+    lds_free = stage_scene(p, lds_free, sc);
     __builtin_assume(sc.wide != nullptr);
   } else {
     sc.wide = nullptr;
   }
+  const float* cam_lds = stage_camera(p, lds_free);
 #ifdef PT_PROFILE
   if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
   __syncthreads();
@@ -644,7 +664,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
               ps.flags &= ~kFoldPending;
             }
             if (local >= sl.count) { keep = false; break; }
-            generate_path(p.cam, rc, hash_sample_index(p, sl, local), p.width, p.height,
+            generate_path(lds_camera(cam_lds), rc, hash_sample_index(p, sl, local), p.width, p.height,
                           start_seed(p, sl, local, ps.seed), ps);
             local++;
           }
@@ -727,6 +747,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
   const uint32_t lane = threadIdx.x & 63u;
   float* dq = reinterpret_cast<float*>(lds_free) + (size_t)(threadIdx.x >> 6) * kDeferWords;  // this wave's queue
   float* late = dq + kDeferFields * kDeferCap;                                                // [3][64]
+  const float* cam_lds = stage_camera(p, reinterpret_cast<float*>(lds_free) + (size_t)(blockDim.x >> 6) * kDeferWords);
   const ShadeParams sp = shade_params(p);
   uint32_t rays_rad = 0, rays_sh = 0, captured = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) p.counters[cnt.clear] = 0u;
@@ -781,13 +802,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
       sr.valid = false;
       if (active) { PT_PROF(PF_BOUNCE); }
       PT_TIC(t_regen);
-#ifdef PT_X_REGEN_MIN
-      const bool regen_now = (uint32_t)__popcll(__ballot(active && !(ps.flags & kAlive))) >= (uint32_t)PT_X_REGEN_MIN ||
-                             __ballot(active && (ps.flags & kAlive)) == 0ull;
-#else
-      const bool regen_now = true;
-#endif
-      if (regen_now && active && !(ps.flags & kAlive)) {
+      if (active && !(ps.flags & kAlive)) {
         PT_PROF(PF_REGEN);
         if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's sum
           q4 acc = p.acc[pixel];
@@ -799,17 +814,13 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
           keep = false;
           active = false;
         } else {
-          generate_path(p.cam, rc, hash_sample_index(p, sl, local), p.width, p.height,
+          generate_path(lds_camera(cam_lds), rc, hash_sample_index(p, sl, local), p.width, p.height,
                         start_seed(p, sl, local, ps.seed), ps);
           local++;
         }
       }
       PT_TOC(t_regen, PT_T_REGEN);
-#ifdef PT_X_REGEN_MIN
-      if (active && (ps.flags & kAlive)) {
-#else
       if (active) {
-#endif
         rc.s = hash_sample_index(p, sl, local - 1);
         PT_TIC(t_trace);
         const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth, ps.origin);
@@ -913,6 +924,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
 //
 // RenderParams::fresh_queue: every slot of the queue is untouched (a fixed-count render's only launch): nothing is
 // loaded for it.  RenderParams::last_pass: no slot will run again after this launch: only its totals are written.
+
 constexpr uint32_t kPersistGrab = 64;  // queue entries a wave takes from the shared counter at a time
 // per wave: the shadow queue (owner and origin share a word: 11 fields), credits, finished-sample sums, last-entry marks
 constexpr uint32_t kPersistWords = (kDeferFields - 1u) * kDeferCap + 2u * kDeferSet + 64u;
@@ -944,6 +956,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   const ShadeParams sp = shade_params(p);
   uint32_t rays_rad = 0, rays_sh = 0, captured = 0;
   const bool fresh = p.fresh_queue != 0, last_pass = p.last_pass != 0;
+  const float* cam_lds = stage_camera(p, reinterpret_cast<float*>(lds_free) + (size_t)(blockDim.x >> 6) * kPersistWords);
 
   auto trace_deferred = [&](uint32_t e) {
     const f3 o = mk3(dq[0 * kDeferCap + e], dq[1 * kDeferCap + e], dq[2 * kDeferCap + e]);
@@ -1052,7 +1065,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
       if (local >= sl.count) {
         retiring = true;
       } else {
-        generate_path(p.cam, rc, hash_sample_index(p, sl, local), p.width, p.height, start_seed(p, sl, local, ps.seed), ps);
+        generate_path(lds_camera(cam_lds), rc, hash_sample_index(p, sl, local), p.width, p.height, start_seed(p, sl, local, ps.seed), ps);
         local++;
       }
     }
@@ -1360,7 +1373,7 @@ static size_t lds_scene_limit() {
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, QueueCounters cnt, const LaunchCfg& c) {
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
   const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
-  size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0);
+  size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0) + kCamLdsBytes;
   const bool defer = p.defer_shadow && !p.acc2;
   if (defer) lds += (size_t)(c.threads / 64) * kDeferWords * sizeof(float);
   const bool g = p.guiding != 0, t = p.train != nullptr;
@@ -1384,7 +1397,7 @@ static size_t persist_lds_bytes(const RenderParams& p, int threads, bool& lds_sc
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
   lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
   return (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) +
-         (size_t)(threads / 64) * kPersistWords * sizeof(float);
+         (size_t)(threads / 64) * kPersistWords * sizeof(float) + kCamLdsBytes;
 }
 // The whole of queue qin (its length in counters[cnt_in]) in one launch; counters[CNT_GRAB] must be zero.
 void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c) {
@@ -1411,7 +1424,7 @@ int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out, bool o
   }
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
   const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
-  size_t lds = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0);
+  size_t lds = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) + kCamLdsBytes;
   const bool defer = p.defer_shadow && !p.acc2;
   if (defer) lds += (size_t)(threads / 64) * kDeferWords * sizeof(float);
   if (lds_out) *lds_out = lds;

@@ -86,18 +86,18 @@ bench.py's HIP-event average for the fused kernel in the same run: {r['avg_launc
 
     # static issue cost of the fused kernel's instruction mix
     isa = subprocess.run([sys.executable, "tools/isa_cost.py", "rust-pathtracer_amd/build/pt_kernels.s",
-                          "_ZN2pt14k_bounce_deferILb0ELb0ELb1E", "12"], capture_output=True, text=True, check=True).stdout
+                          "_ZN2pt16k_bounce_persistILb0ELb0ELb1E", "12"], capture_output=True, text=True, check=True).stdout
     open("profiles/r03_isa_cost_fused.txt", "w").write(isa)
     issue_cost = float(re.search(r"([\d.]+) cycles per VALU instruction", isa).group(1))
 
-    tot = counters(rd("pmc_fused_summary.txt"), "k_bounce_defer")
+    tot = counters(rd("pmc_fused_summary.txt"), "k_bounce_persist")
     fetch, write = tot["FETCH_SIZE"][1], tot["WRITE_SIZE"][1]
     rays_per_step = final["roofline"]["rays_per_launch"] * final["roofline"]["launches"] / final["steps"]
     json.dump({"fused": {
         "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
         "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
         "correction": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads); WRITE_SIZE as reported",
-        "workload": f"cornell_1920x1080_1024spp_depth32_converge, {tot['FETCH_SIZE'][2]} launches of k_bounce_defer",
+        "workload": f"cornell_1920x1080_1024spp_depth32_converge, {tot['FETCH_SIZE'][2]} launches of k_bounce_persist (one per step)",
         # SIMD cycles that went by per VALU wave-instruction issued (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs)
         "simd_cycles_per_valu_inst": 1024 * (tot["GRBM_GUI_ACTIVE"][0] / 8) / tot["SQ_INSTS_VALU"][0],
         # what the kernel's instruction mix costs to issue, unweighted over the kernel's text (tools/isa_cost.py with
