@@ -1,10 +1,13 @@
 #!/bin/bash
-# The measurements behind profiles/r03_*: one GPU call.  Run from the repository root.
+# The measurements behind profiles/r03_*: tools/r03_collect.sh a | b | c, one GPU call each (a: the default scene,
+# b: the large scene, c: the rest).  Run from the repository root; tools/r03_profiles.py files the results.
 # Every rocprofv3 step is its own run under its own time limit; counters never share a run with a trace.
 export TMPDIR=/tmp
 set -e
 OUT=gpurun_out/r03
 mkdir -p $OUT
+PART=${1:-abc}
+if [[ $PART == *a* ]]; then
 # 1. kernel trace + stats of the bench command (fused, 1080p 1024 spp, one step)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_f -o pf -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-boundary --no-large-scene > $OUT/bench_profiled.json 2> $OUT/prof_f.err
 # 2. PMC passes of the same command
@@ -23,6 +26,11 @@ GUIDED=1 timeout -k 10 200 python3 tools/sections.py 128 > $OUT/sections_guided.
 timeout -k 10 200 python3 tools/configs.py > $OUT/configs.txt 2>&1
 timeout -k 10 200 python3 tools/adaptive_time.py > $OUT/adaptive_time.txt 2>&1
 timeout -k 10 200 python3 tools/demosaic_time.py > $OUT/demosaic_time.txt 2>&1
+# the plain bench line; two ranks on the one GPU over gloo (the N > 1 code path: strong scaling, all-reduce timing)
+timeout -k 10 300 python3 bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err
+BENCH_BACKEND=gloo timeout -k 10 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_two_ranks_gloo.json 2> $OUT/bench_two_ranks_gloo.err
+fi
+if [[ $PART == *b* ]]; then
 # 12.8 M triangles two ways: 2 500 spheres of 5 120 triangles (the scene of the earlier profiles) and 40 000 of 320
 timeout -k 10 300 python3 tools/bigscene.py 2500 4 3840 2160 16 > $OUT/bigscene.txt 2>&1
 timeout -k 10 300 python3 tools/bigscene_stats.py 2500 4 3840 2160 16 > $OUT/bigscene_stats.txt 2>&1
@@ -37,15 +45,16 @@ runb tcp1 TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LAT
 runb fetch FETCH_SIZE
 runb grbm GRBM_GUI_ACTIVE
 python3 tools/pmc_summary.py $OUT/pmc_big > $OUT/pmc_big_summary.txt
-# 6. the plain bench line; two ranks on the one GPU over gloo (the N > 1 code path: strong scaling, all-reduce timing)
-timeout -k 10 300 python3 bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err
-BENCH_BACKEND=gloo timeout -k 10 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_two_ranks_gloo.json 2> $OUT/bench_two_ranks_gloo.err
+fi
+if [[ $PART == *c* ]]; then
 # 7. this round's additions: thresholded test quantities, parity report, occupancy, adaptive rounds, small and mid-size scenes
 timeout -k 10 300 python3 -u tools/threshold_probe.py > $OUT/threshold_probe.json 2> $OUT/threshold_probe.err
 timeout -k 10 200 python3 -u tools/parity_report.py > $OUT/parity_report.json 2> $OUT/parity_report.err
 timeout -k 10 100 python3 -u tools/occupancy.py > $OUT/occupancy.txt 2>&1
 PT_ADAPTIVE_TRACE=1 timeout -k 10 100 python3 -u tools/adaptive_one.py 1 0.01 > $OUT/adaptive_rounds.txt 2>&1
+rm -f $OUT/small_scenes.txt
 for cfg in "1 1" "2 2" "5 2" "10 2" "20 2" "50 2"; do echo "== scene $cfg" >> $OUT/small_scenes.txt; PIPES=0,1 timeout -k 10 120 python3 -u tools/bigscene_spp.py $cfg 1920 1080 256 2>&1 | grep pipe >> $OUT/small_scenes.txt; done
 timeout -k 10 900 bash tools/midsize_sweep.sh > $OUT/midsize.txt 2>&1
 timeout -k 10 200 python3 -u tools/config4_full.py > $OUT/config4_full.txt 2>&1
-echo collected
+fi
+echo collected $PART
