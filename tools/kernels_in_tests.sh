@@ -1,5 +1,5 @@
 #!/bin/bash
-# Which kernels the GPU test suite launches (profiles/r02_kernels_in_tests.md): a kernel trace of pytest in one
+# Which kernels the GPU test suite launches (profiles/rNN_kernels_in_tests.md): a kernel trace of pytest in one
 # process; the tests that start other processes (two ranks, the host driver) are left out of the traced run.
 export TMPDIR=/tmp
 set -e
