@@ -133,9 +133,10 @@ __device__ __forceinline__ uint32_t wave_append_slot(bool keep, uint32_t* counte
 }
 
 // Adaptive sampling keeps the per-channel sum of squared sample values beside the sum.
+__device__ __forceinline__ void add_squares(q4& a, f3 v) { a.x += v.x * v.x; a.y += v.y * v.y; a.z += v.z * v.z; }
 __device__ __forceinline__ void fold_squares(q4* acc2, uint32_t slot, f3 v) {
   q4 a = acc2[slot];
-  a.x += v.x * v.x; a.y += v.y * v.y; a.z += v.z * v.z;
+  add_squares(a, v);
   acc2[slot] = a;
 }
 
@@ -603,6 +604,7 @@ __device__ __forceinline__ u4* stage_scene(const RenderParams& p, u4* dst, Scene
 // register and fetches it back lane by lane (v_readlane) inside the loop.  With the camera out of the way the
 // one-launch kernel spills 10 scalar registers instead of 33 and runs 1.4 % faster.
 constexpr uint32_t kCamLdsBytes = 64;
+constexpr uint32_t kTotalsWords = 8;  // k_bounce: a slot's sum and sum of squares (two q4) per thread, in LDS
 __device__ __forceinline__ const float* stage_camera(const RenderParams& p, void* at) {  // whole block; ends with a barrier
   float* c = reinterpret_cast<float*>(at);
   if (threadIdx.x < 12u) c[threadIdx.x] = reinterpret_cast<const float*>(&p.cam)[threadIdx.x];
@@ -632,6 +634,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
     sc.wide = nullptr;
   }
   const float* cam_lds = stage_camera(p, lds_free);
+  // The slot's totals (sum, and sum of squares in adaptive renders) wait in LDS while the launch runs: a finished
+  // sample is added there, in the order and with the rounding it would be added to the arrays in memory, and the
+  // totals go back once, with the path state -- not a load, a wait and a store per sample inside the bounce loop.
+  float* tot = reinterpret_cast<float*>(lds_free) + kCamLdsBytes / sizeof(float) + threadIdx.x;  // [8][blockDim]
+  const uint32_t ts = blockDim.x;
 #ifdef PT_PROFILE
   if (threadIdx.x < 64) g_prof_lds[threadIdx.x] = 0u;
   __syncthreads();
@@ -651,16 +658,26 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
       const Slot sl = decode_slot(p, pixel);
       keep = (ps.flags & (kAlive | kFoldPending)) || local < sl.count;
       if (keep) {
+        {
+          const q4 a = p.acc[pixel];
+          tot[0] = a.x; tot[ts] = a.y; tot[2u * ts] = a.z; tot[3u * ts] = a.w;
+          if (p.acc2) {
+            const q4 b = p.acc2[pixel];
+            tot[4u * ts] = b.x; tot[5u * ts] = b.y; tot[6u * ts] = b.z; tot[7u * ts] = b.w;
+          }
+        }
         RandCtx rc = make_rand_ctx(sl.x, sl.y, 0, p.frame);  // the pixel's noise shift: once per launch
         for (int b = 0; b < bounces; ++b) {
           PT_PROF(PF_BOUNCE);
           if (!(ps.flags & kAlive)) {
             PT_PROF(PF_REGEN);
-            if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the pixel's sum
-              q4 acc = p.acc[pixel];
-              acc.x += ps.sum.x; acc.y += ps.sum.y; acc.z += ps.sum.z;
-              p.acc[pixel] = acc;
-              if (p.acc2) fold_squares(p.acc2, pixel, ps.sum);
+            if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's totals
+              tot[0] += ps.sum.x; tot[ts] += ps.sum.y; tot[2u * ts] += ps.sum.z;
+              if (p.acc2) {
+                q4 b = q4{tot[4u * ts], tot[5u * ts], tot[6u * ts], 0.0f};
+                add_squares(b, ps.sum);
+                tot[4u * ts] = b.x; tot[5u * ts] = b.y; tot[6u * ts] = b.z;
+              }
               ps.flags &= ~kFoldPending;
             }
             if (local >= sl.count) { keep = false; break; }
@@ -685,6 +702,8 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce(RenderParams p,
         // a path that ended on the last bounce of this launch is folded by the next launch
         store_state(p, pixel, ps);
         p.started[pixel] = local;
+        p.acc[pixel] = q4{tot[0], tot[ts], tot[2u * ts], tot[3u * ts]};
+        if (p.acc2) p.acc2[pixel] = q4{tot[4u * ts], tot[5u * ts], tot[6u * ts], tot[7u * ts]};
       }
     }
     if (compact) {
@@ -1376,6 +1395,7 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, Que
   size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0) + kCamLdsBytes;
   const bool defer = p.defer_shadow && !p.acc2;
   if (defer) lds += (size_t)(c.threads / 64) * kDeferWords * sizeof(float);
+  else lds += (size_t)c.threads * kTotalsWords * sizeof(float);
   const bool g = p.guiding != 0, t = p.train != nullptr;
   if (g && t) launch_bounce_t<true, true>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
   else if (g) launch_bounce_t<true, false>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
@@ -1427,6 +1447,7 @@ int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out, bool o
   size_t lds = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) + kCamLdsBytes;
   const bool defer = p.defer_shadow && !p.acc2;
   if (defer) lds += (size_t)(threads / 64) * kDeferWords * sizeof(float);
+  else lds += (size_t)threads * kTotalsWords * sizeof(float);
   if (lds_out) *lds_out = lds;
   int n = 0;
   const hipError_t e = defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_defer<false, false, true>, threads, lds)
