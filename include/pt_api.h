@@ -148,19 +148,20 @@ PT_EXPORT void pt_set_adaptive_chunks(int chunks);
 PT_EXPORT int  pt_get_adaptive_chunks(void);
 PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
 
-/* Fused pipeline only.  on (default, env PT_DEFER_SHADOW=1): each wave queues its shadow rays in LDS
- * and traces them 64 at a time, at full occupancy of the wave; a slot's total is the same set of
- * terms added in a different order, so images agree with the staged pipeline to rounding (same
- * paths).  off: shadow rays are traced where they are made and the two pipelines agree bit for bit.
- * Adaptive renders always trace in place (the noise test needs per-sample sums; a queued form that kept them
- * was measured 10 % slower than tracing in place). */
+/* Fused pipeline only.  off (default, env PT_DEFER_SHADOW=0): shadow rays are traced where they are made, a slot's
+ * samples are added in sample order, and the fused and the staged pipeline agree bit for bit.  on: each wave queues
+ * its shadow rays in LDS and traces them 64 at a time, at full occupancy of the wave; a slot's total is the same
+ * set of terms added in a different order, so images agree with the staged pipeline to rounding (same paths).
+ * The queue was worth 12 % when traversal cost half again as much as it does now; on the present kernels it costs
+ * 3 % (1080p, 1024 spp: 325 ms in place, 335 ms queued).  Adaptive renders always trace in place (the noise test
+ * needs per-sample sums). */
 PT_EXPORT void pt_set_defer_shadow(int on);
 PT_EXPORT int  pt_get_defer_shadow(void);
-/* Fused pipeline, renders with deferred shadow rays and a fixed sample count.  on (default, env PT_PERSIST=1): the
- * whole render is one kernel launch; its waves take slots from a shared counter and a lane that has finished a slot
- * takes the next one, so no path state goes through memory (1 % faster at 1024 samples a pixel, 3 % at 128).
- * off: launch after launch, 32 bounces of every slot each.  The same paths either way; a slot's terms are added in
- * a different order, so images agree to rounding. */
+/* Fused pipeline, renders with a fixed sample count.  on (default, env PT_PERSIST=1): the whole render is one
+ * kernel launch; its waves take slots from a shared counter and a lane that has finished a slot takes the next
+ * one, so no path state goes through memory (4 % faster at 1024 samples a pixel than launch after launch).
+ * off: launch after launch, 32 bounces of every slot each.  The same paths and, with shadow rays traced in place,
+ * the same bits either way. */
 PT_EXPORT void pt_set_one_launch(int on);
 PT_EXPORT int  pt_get_one_launch(void);
 

@@ -946,10 +946,12 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
 
 constexpr uint32_t kPersistGrab = 64;  // queue entries a wave takes from the shared counter at a time
 // per wave: the shadow queue (owner and origin share a word: 11 fields), credits, finished-sample sums, last-entry marks
-constexpr uint32_t kPersistWords = (kDeferFields - 1u) * kDeferCap + 2u * kDeferSet + 64u;
+__host__ __device__ constexpr uint32_t persist_words(bool defer) {
+  return defer ? (kDeferFields - 1u) * kDeferCap + 2u * kDeferSet + 64u : kDeferSet;
+}
 constexpr uint32_t kPersistOriginBits = 26;  // a shadow ray's origin primitive (+1) beside its owner lane in one word
 
-template <bool GUIDED, bool TRAIN, bool LDS_SCENE>
+template <bool GUIDED, bool TRAIN, bool LDS_SCENE, bool DEFER>
 __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderParams p, int qin, int cnt_in) {
   const uint32_t n = p.counters[cnt_in];
   const uint32_t* q_in = p.queue[qin];
@@ -968,14 +970,14 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
 #endif
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
-  float* dq = reinterpret_cast<float*>(lds_free) + (size_t)(threadIdx.x >> 6) * kPersistWords;  // this wave's queue
+  float* dq = reinterpret_cast<float*>(lds_free) + (size_t)(threadIdx.x >> 6) * persist_words(DEFER);  // this wave's queue
   float* late = dq + (kDeferFields - 1u) * kDeferCap;                       // [3][64]: credits of the lane's slot
-  float* done_sum = late + kDeferSet;                                       // [3][64]: its finished samples
+  float* done_sum = DEFER ? late + kDeferSet : dq;                          // [3][64]: its finished samples
   uint32_t* last_entry = reinterpret_cast<uint32_t*>(done_sum + kDeferSet); // [64]: 1 + position of its last queued ray
   const ShadeParams sp = shade_params(p);
   uint32_t rays_rad = 0, rays_sh = 0, captured = 0;
   const bool fresh = p.fresh_queue != 0, last_pass = p.last_pass != 0;
-  const float* cam_lds = stage_camera(p, reinterpret_cast<float*>(lds_free) + (size_t)(blockDim.x >> 6) * kPersistWords);
+  const float* cam_lds = stage_camera(p, reinterpret_cast<float*>(lds_free) + (size_t)(blockDim.x >> 6) * persist_words(DEFER));
 
   auto trace_deferred = [&](uint32_t e) {
     const f3 o = mk3(dq[0 * kDeferCap + e], dq[1 * kDeferCap + e], dq[2 * kDeferCap + e]);
@@ -1007,9 +1009,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   ps.origin = 0u;
   Slot sl = decode_slot(p, 0u);
   RandCtx rc = make_rand_ctx(0, 0, 0, p.frame);
-  late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
+  if (DEFER) {
+    late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
+    last_entry[lane] = 0u;
+  }
   done_sum[lane] = 0.0f; done_sum[64u + lane] = 0.0f; done_sum[128u + lane] = 0.0f;
-  last_entry[lane] = 0u;
   // the same on every lane of the wave
   uint32_t head = 0, waiting = 0, queued_total = 0, traced_total = 0;  // the LDS queue
   uint32_t grab_pos = 0, grab_end = 0;                                  // the stretch of the slot queue the wave holds
@@ -1017,17 +1021,22 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   PT_TIC(t_loop);
   for (;;) {
     // a slot whose last sample is folded and whose queued rays are all traced goes back to memory
-    if (has_slot && retiring && traced_total >= last_entry[lane]) {
-      // total = what the slot held before + its samples of this launch in order + their credits in queue order
+    if (has_slot && retiring && (!DEFER || traced_total >= last_entry[lane])) {
+      // DEFER: total = what the slot held before + its samples of this launch in order + their credits in queue order;
+      // else the samples were added, in order, to what the slot held before
       f3 v = mk3(done_sum[lane], done_sum[64u + lane], done_sum[128u + lane]);
-      v += mk3(late[lane], late[64u + lane], late[128u + lane]);
       q4 acc = q4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (!fresh) acc = p.acc[pixel];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z;
+      if (DEFER) {
+        v += mk3(late[lane], late[64u + lane], late[128u + lane]);
+        if (!fresh) acc = p.acc[pixel];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z;
+        late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
+        last_entry[lane] = 0u;
+      } else {
+        acc.x = v.x; acc.y = v.y; acc.z = v.z;
+      }
       p.acc[pixel] = acc;
-      late[lane] = 0.0f; late[64u + lane] = 0.0f; late[128u + lane] = 0.0f;
       done_sum[lane] = 0.0f; done_sum[64u + lane] = 0.0f; done_sum[128u + lane] = 0.0f;
-      last_entry[lane] = 0u;
       if (!last_pass) store_state(p, pixel, ps);
       p.started[pixel] = local;
       has_slot = false;
@@ -1057,6 +1066,10 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
           } else {
             ps = load_state(p, pixel);
             local = p.started[pixel];
+            if (!DEFER) {
+              const q4 a = p.acc[pixel];
+              done_sum[lane] = a.x; done_sum[64u + lane] = a.y; done_sum[128u + lane] = a.z;
+            }
           }
           sl = decode_slot(p, pixel);
           rc = make_rand_ctx(sl.x, sl.y, 0, p.frame);  // the pixel's noise shift: once per slot
@@ -1100,8 +1113,14 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
       shade_hit<GUIDED, TRAIN>(sc, p.guide, sp, rc, ps, h, sr, tv);
       if (TRAIN) capture_train(p, tv, ps.seed, pixel, captured);
       PT_TOC(t_shade, PT_T_SHADE);
+      if (!DEFER && sr.valid) {
+        PT_PROF(PF_SHADOW);
+        rays_sh++;
+        const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth, sr.origin);
+        if (o.prim < 0) ps.sum += sr.contrib;
+      }
     }
-    {
+    if (DEFER) {
       PT_TIC(t_enq);
       const unsigned long long made = __ballot(sr.valid);
       if (sr.valid) {
@@ -1404,30 +1423,41 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, Que
   PT_KCHECK();
 }
 template <bool GUIDED, bool TRAIN>
-static void launch_persist_t(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c, bool lds_scene, size_t lds) {
-  if (lds_scene) k_bounce_persist<GUIDED, TRAIN, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
-  else k_bounce_persist<GUIDED, TRAIN, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+static void launch_persist_t(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c, bool lds_scene, bool defer, size_t lds) {
+  if (defer) {
+    if (lds_scene) k_bounce_persist<GUIDED, TRAIN, true, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+    else k_bounce_persist<GUIDED, TRAIN, false, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+  } else {
+    if (lds_scene) k_bounce_persist<GUIDED, TRAIN, true, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+    else k_bounce_persist<GUIDED, TRAIN, false, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+  }
 }
-// k_bounce_persist carries what k_bounce_defer carries: renders with deferred shadow rays and no per-sample sums
-// (a shadow ray's origin primitive shares a word with its owner lane, which bounds the triangle count).
-bool bounce_persist_usable(const RenderParams& p) {
-  return p.defer_shadow && !p.acc2 && p.scene.num_tris < (1u << kPersistOriginBits) - 1u;
+// The deferred form: a shadow ray's origin primitive shares a word with its owner lane, which bounds the triangle
+// count; beyond it shadow rays are traced in place.
+static bool persist_defers(const RenderParams& p) {
+  return p.defer_shadow && p.scene.num_tris < (1u << kPersistOriginBits) - 1u;
 }
+// k_bounce_persist keeps no per-sample sums: renders that need them (adaptive) go launch after launch.  A form
+// that kept them was measured on the long rounds of an adaptive render (32 samples per slot and more) and gained
+// nothing, 345.6 against 345.8 ms: a slot that is picked up again has its state to load when a lane takes it,
+// one lane's trip to memory that the whole wave waits for.
+bool bounce_persist_usable(const RenderParams& p) { return !p.acc2; }
 static size_t persist_lds_bytes(const RenderParams& p, int threads, bool& lds_scene) {
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
   lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
   return (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) +
-         (size_t)(threads / 64) * kPersistWords * sizeof(float) + kCamLdsBytes;
+         (size_t)(threads / 64) * persist_words(persist_defers(p)) * sizeof(float) + kCamLdsBytes;
 }
 // The whole of queue qin (its length in counters[cnt_in]) in one launch; counters[CNT_GRAB] must be zero.
 void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c) {
   bool lds_scene;
   const size_t lds = persist_lds_bytes(p, c.threads, lds_scene);
   const bool g = p.guiding != 0, t = p.train != nullptr;
-  if (g && t) launch_persist_t<true, true>(p, qin, cnt_in, c, lds_scene, lds);
-  else if (g) launch_persist_t<true, false>(p, qin, cnt_in, c, lds_scene, lds);
-  else if (t) launch_persist_t<false, true>(p, qin, cnt_in, c, lds_scene, lds);
-  else launch_persist_t<false, false>(p, qin, cnt_in, c, lds_scene, lds);
+  const bool defer = persist_defers(p);
+  if (g && t) launch_persist_t<true, true>(p, qin, cnt_in, c, lds_scene, defer, lds);
+  else if (g) launch_persist_t<true, false>(p, qin, cnt_in, c, lds_scene, defer, lds);
+  else if (t) launch_persist_t<false, true>(p, qin, cnt_in, c, lds_scene, defer, lds);
+  else launch_persist_t<false, false>(p, qin, cnt_in, c, lds_scene, defer, lds);
   PT_KCHECK();
 }
 // Resident blocks per CU of the fused kernel launch_bounce would pick for these parameters, as the runtime counts
@@ -1438,8 +1468,13 @@ int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out, bool o
     const size_t lds = persist_lds_bytes(p, threads, lds_scene);
     if (lds_out) *lds_out = lds;
     int n = 0;
-    const hipError_t e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, true>, threads, lds)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, false>, threads, lds);
+    hipError_t e;
+    if (persist_defers(p))
+      e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, true, true>, threads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, false, true>, threads, lds);
+    else
+      e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, true, false>, threads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, false, false>, threads, lds);
     return e == hipSuccess ? n : -1;
   }
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);

@@ -46,7 +46,7 @@ std::mutex g_stats_mutex;        // ray totals are added from every shard's host
 KernelStat g_kstats[PT_K_COUNT];
 uint64_t g_rays_total[2] = {0, 0};
 int g_fused_bounces = 32;  // bounces per fused launch (1080p, 1024 spp: 16 389.7 ms, 24 382.0, 32 382.7, 48 382.2, 64 388.4)
-int g_defer_shadow = getenv("PT_DEFER_SHADOW") ? atoi(getenv("PT_DEFER_SHADOW")) : 1;
+int g_defer_shadow = getenv("PT_DEFER_SHADOW") ? atoi(getenv("PT_DEFER_SHADOW")) : 0;
 int g_one_launch = getenv("PT_PERSIST") ? (atoi(getenv("PT_PERSIST")) != 0) : 1;
 int g_adaptive_round = getenv("PT_ADAPTIVE_ROUND") ? atoi(getenv("PT_ADAPTIVE_ROUND")) : -32;
 int g_adaptive_chunks = getenv("PT_ADAPTIVE_CHUNKS") ? atoi(getenv("PT_ADAPTIVE_CHUNKS")) : 0;  // 0: as many as fit
@@ -581,8 +581,8 @@ struct RenderLoop {
     init[CNT_Q0] = n;
     HIP_CHECK(hipMemcpyAsync(s.counters, init, CNT_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
     static const int fused_bounces = getenv("PT_FUSED_BOUNCES") ? atoi(getenv("PT_FUSED_BOUNCES")) : g_fused_bounces;
-    // Renders without per-sample sums and with deferred shadow rays take the whole queue in one launch;
-    // PT_PERSIST=0: they too go launch after launch (32 bounces of every slot per launch, queue compacted).
+    // Renders without per-sample sums take the whole queue in one launch; pt_set_one_launch(0) / PT_PERSIST=0: they
+    // too go launch after launch (32 bounces of every slot per launch, queue compacted).
     const bool persist = g_one_launch != 0 && bounce_persist_usable(p);
     bool use_fused = fused, done = false;
     int qin = 0, slot = 0;

@@ -17,6 +17,8 @@ GOLD = os.path.join(HERE, "golden")
 ROOT = os.path.dirname(HERE)
 
 
+DEFER_DEFAULT = 0  # shadow rays are traced in place unless pt_set_defer_shadow(1) / PT_DEFER_SHADOW=1 says otherwise
+
 def rel_rmse(img, ref):
     """sqrt(mean(((I-R)/(R+0.01))^2)) per the measurement plan."""
     return float(np.sqrt(np.mean(((img - ref) / (ref + 0.01)) ** 2)))
@@ -236,7 +238,7 @@ def test_trace_synthetic_scene_matches_brute_force(gpu, oracle):
         OL.orc_scene_set(None, 0, None, 0, None)
         L.pt_scene_cornell()
         L.pt_set_pipeline(1)
-        L.pt_set_defer_shadow(1)
+        L.pt_set_defer_shadow(DEFER_DEFAULT)
 
 
 def test_awkward_geometry_is_sound(gpu):
@@ -879,48 +881,46 @@ def test_strict_mismatches_are_the_rays_that_start_on_a_plane(gpu, oracle):
 
 
 def test_pipelines_agree_and_are_deterministic(gpu):
+    """The staged kernels, the fused kernel launch after launch and the fused kernel as one launch (the default:
+    its lanes take slot after slot from a shared counter, so which wave carries which slot differs from run to run)
+    render the same bits: the kernels are compiled with products and sums fused per source expression only, so they
+    round every operation alike and take the same paths, and every form adds a slot's samples in sample order.
+    With shadow rays queued per wave and traced 64 at a time (pt_set_defer_shadow(1)) the paths and the terms per
+    pixel are the same and the order of additions is not: run-to-run identical, equal to rounding."""
     L = gpu.lib()
-    imgs = []
-    L.pt_set_defer_shadow(0)
-    for pipeline in (0, 1, 1):
-        L.pt_set_pipeline(pipeline)
+    assert L.pt_get_one_launch() == 1 and L.pt_get_defer_shadow() == DEFER_DEFAULT == 0
+
+    def render(w, h, spp):
         L.pt_set_frame(4)
-        imgs.append(gpu.render_rgb(96, 54, 32))
-    assert np.array_equal(imgs[1], imgs[2])  # run-to-run bit identical
-    # the kernels are compiled with products and sums fused per source expression only, so the staged
-    # and the fused pipelines round every operation alike and take the same paths
-    assert np.array_equal(imgs[0], imgs[1])
-    # default fused kernel: shadow rays traced 64 at a time from a per-wave queue -- the same paths and
-    # the same terms per pixel, added in a different order
-    # and in either launch form: the whole render as one launch whose lanes take slot after slot (the default; which
-    # wave carries which slot differs from run to run, the slot's total does not), or launch after launch
-    L.pt_set_defer_shadow(1)
-    assert L.pt_get_one_launch() == 1
-    for one_launch in (0, 1):
-        L.pt_set_one_launch(one_launch)
-        deferred = []
-        for _ in range(2):
-            L.pt_set_frame(4)
-            L.pt_reset_ray_counts()
-            deferred.append(gpu.render_rgb(96, 54, 32))
-            rays_deferred = gpu.ray_counts()
-        assert np.array_equal(deferred[0], deferred[1])
-        assert np.allclose(deferred[0], imgs[1], rtol=2e-5, atol=1e-7)
-        # enough slots that every wave refills many times, and more than one chunk
-        big = []
-        for _ in range(2):
-            L.pt_set_frame(4)
-            big.append(gpu.render_rgb(1280, 720, 64))
-        assert np.array_equal(big[0], big[1])
-        if one_launch == 0:
-            big_launches = big[0]
-    assert np.allclose(big[0], big_launches, rtol=2e-5, atol=1e-7)
-    L.pt_set_defer_shadow(0)
-    L.pt_set_frame(4)
-    L.pt_reset_ray_counts()
-    gpu.render_rgb(96, 54, 32)
-    assert gpu.ray_counts() == rays_deferred
-    L.pt_set_defer_shadow(1)
+        L.pt_reset_ray_counts()
+        img = gpu.render_rgb(w, h, spp)
+        return img, gpu.ray_counts()
+
+    try:
+        L.pt_set_pipeline(0)
+        staged, rays = render(96, 54, 32)
+        staged_big, rays_big = render(1280, 720, 64)  # enough slots that every wave refills many times; two chunks
+        L.pt_set_pipeline(1)
+        for defer in (0, 1):
+            L.pt_set_defer_shadow(defer)
+            for one_launch in (1, 0):
+                L.pt_set_one_launch(one_launch)
+                for _ in range(2):
+                    img, r = render(96, 54, 32)
+                    big, rb = render(1280, 720, 64)
+                    assert r == rays and rb == rays_big
+                    if defer == 0:
+                        assert np.array_equal(img, staged) and np.array_equal(big, staged_big)
+                    else:
+                        assert np.allclose(img, staged, rtol=2e-5, atol=1e-7) and np.allclose(big, staged_big, rtol=2e-5, atol=1e-7)
+                        if _ == 0:
+                            first = (img, big)
+                        else:
+                            assert np.array_equal(img, first[0]) and np.array_equal(big, first[1])
+    finally:
+        L.pt_set_pipeline(1)
+        L.pt_set_one_launch(1)
+        L.pt_set_defer_shadow(DEFER_DEFAULT)
 
 
 @pytest.mark.parametrize("pipeline", [0, 1])
@@ -1610,7 +1610,6 @@ def test_large_scene_at_its_own_size(gpu):
         assert np.isfinite(imgs[0]).all() and imgs[0].min() >= 0 and imgs[0].mean() > 0.01
         assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[1], imgs[2])
         assert 2.0 < rays[0] / (w * h * 2) < 12.0
-        L.pt_set_defer_shadow(1)
         L.pt_set_pipeline(-1)
         L.pt_set_frame(11)
         again = gpu.render_rgb(w, h, 2)
@@ -1628,7 +1627,7 @@ def test_large_scene_at_its_own_size(gpu):
     finally:
         L.pt_scene_cornell()
         L.pt_set_pipeline(1)
-        L.pt_set_defer_shadow(1)
+        L.pt_set_defer_shadow(DEFER_DEFAULT)
 
 
 def test_adaptive_render_of_a_scene_that_runs_staged(gpu):
@@ -1664,7 +1663,7 @@ def test_adaptive_render_of_a_scene_that_runs_staged(gpu):
     finally:
         L.pt_scene_cornell()
         L.pt_set_pipeline(1)
-        L.pt_set_defer_shadow(1)
+        L.pt_set_defer_shadow(DEFER_DEFAULT)
 
 
 def test_one_sample_chunks_are_independent_between_pixels(gpu):

@@ -41,7 +41,7 @@ for pipeline in (0, 1):
                 "mean_ratio": float(img.mean() / o_img.mean())}
 L.pt_set_adaptive_round(-32)
 L.pt_set_adaptive_chunks(0)
-L.pt_set_defer_shadow(1)
+L.pt_set_defer_shadow(0)
 L.pt_set_pipeline(1)
 
 # smoke()'s quantities
