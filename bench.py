@@ -269,11 +269,19 @@ def main():
                                        "350 per opaque shading step, transcendentals as 1), not a counter",
                     lane_insts_per_ray_counted=(pmc["valu_insts_per_ray"] * 64.0 * pmc["valu_lane_utilisation"])
                     if pmc.get("valu_insts_per_ray") and pmc.get("valu_lane_utilisation") else None,
-                    # SIMD cycles that pass per vector instruction issued, against what this kernel's instruction
-                    # mix costs to issue (tools/isa_cost.py on the kernel's ISA with the per-opcode costs measured by
-                    # tools/valu_ops.hip: 2.4 / 4.2 / 8.2 cycles); lane_util = active lanes per vector instruction / 64
+                    # SIMD cycles that pass per vector instruction issued, against what the instructions cost to
+                    # issue one class at a time (tools/valu_ops.hip: 2.4 cycles for an FMA on registers, 4.2 for
+                    # compares, selects, min/max, conversions, 8.2 for transcendentals).  issue_cost = those costs over
+                    # the mix the counters saw (SQ_INSTS_VALU_*); in a mix the classes overlap a little, so the measured
+                    # figure can fall below it and issue_util is capped at 1.  issue_floor_share = the share of all SIMD
+                    # cycles the issued instructions would need if every one were the cheapest kind.
+                    # lane_util = active lanes per vector instruction / 64
                     simd_cycles_per_valu_inst=cyc, issue_cost_cycles_per_valu_inst=pmc.get("issue_cost_cycles_per_valu_inst"),
-                    issue_util=(pmc.get("issue_cost_cycles_per_valu_inst") / cyc) if cyc and pmc.get("issue_cost_cycles_per_valu_inst") else None,
+                    issue_util=min(1.0, pmc.get("issue_cost_cycles_per_valu_inst") / cyc) if cyc and pmc.get("issue_cost_cycles_per_valu_inst") else None,
+                    issue_floor_share=(2.4 / cyc) if cyc else None,
+                    fp32_flops_issued_per_ray=pmc.get("fp32_flops_issued_per_ray"),
+                    fp32_flops_on_active_lanes_per_ray=pmc.get("fp32_flops_on_active_lanes_per_ray"),
+                    valu_mix=pmc.get("valu_mix"),
                     lane_util=pmc.get("valu_lane_utilisation"), valu_insts_per_ray=pmc.get("valu_insts_per_ray"))
         fused = args.pipeline == "fused"
         result = {

@@ -917,13 +917,16 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
 // lanes stay busy until the queue is empty.  Nothing of a path touches memory between its slot's first and last
 // bounce, and there is no compaction: when the launch ends every slot of the queue has finished.
 //
-// Shadow rays go through the wave's queue in LDS as in k_bounce_defer.  The lane keeps two accumulators in LDS
-// for as long as its slot lives: the sum of the slot's finished samples, in sample order, and the credits of its
+// !DEFER (the default): shadow rays are traced where they are made and a finished sample is added to the slot's
+// sum, which waits in LDS (three words per lane) and starts from what the slot held before: the additions of
+// k_bounce and of the staged kernels in their order, so all three render the same bits.
+// DEFER: shadow rays go through the wave's queue in LDS as in k_bounce_defer.  The lane keeps two accumulators in
+// LDS for as long as its slot lives: the sum of the slot's finished samples, in sample order, and the credits of its
 // unoccluded shadow rays, in queue order; their sum goes to the slot's total when it retires, which it does only
 // after its last queued ray has been traced (two counters per wave -- entries queued, entries traced -- and the
-// position of the lane's last entry tell when; the wait is two iterations out of hundreds).  A slot's result does
-// not depend on the lane or the wave that carried it, or on what shared the wave: renders stay reproducible bit for
-// bit although slots reach lanes in a different order every time.
+// position of the lane's last entry tell when; the wait is two iterations out of hundreds).
+// Either way a slot's result does not depend on the lane or the wave that carried it, or on what shared the wave:
+// renders stay reproducible bit for bit although slots reach lanes in a different order every time.
 //
 // Item tests shared across the wave were built on this kernel and taken out again.  A lane tested its ray's first
 // candidate itself; the candidates left over in the wave went to a list in LDS and were tested 64 pairs at a time by
@@ -937,15 +940,18 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
 //
 // What it costs: a lane refills alone, so the hundred-odd instructions that write one slot back and set up the next
 // run at one lane in 64 where a launch of k_bounce_defer does them for 64 slots at once (+3.3 % vector instructions
-// measured, against 6.3 % fewer loop iterations).  Renders whose slots live long gain little (1 % at 1024 samples a
-// pixel), short ones more (3.4 % at 128: their launches are all head and tail); slots of an adaptive round's 8 or 16
-// samples would refill every few iterations, so adaptive renders stay with k_bounce.
+// measured, against 6.3 % fewer loop iterations).  With shadow rays in place the one launch is 4 % faster than launch
+// after launch at 1024 samples a pixel (324.7 against 338.1 ms), with the queue 1-3 % (more on short renders, whose
+// launches are all head and tail); slots of an adaptive round's 8 or 16 samples would refill every few iterations,
+// and a slot that is picked up again has its state to load, one lane's trip to memory that the wave waits for, so
+// adaptive renders stay with k_bounce.
 //
 // RenderParams::fresh_queue: every slot of the queue is untouched (a fixed-count render's only launch): nothing is
 // loaded for it.  RenderParams::last_pass: no slot will run again after this launch: only its totals are written.
 
 constexpr uint32_t kPersistGrab = 64;  // queue entries a wave takes from the shared counter at a time
-// per wave: the shadow queue (owner and origin share a word: 11 fields), credits, finished-sample sums, last-entry marks
+// per wave: finished-sample sums; DEFER: the shadow queue (owner and origin share a word: 11 fields), credits,
+// finished-sample sums, last-entry marks
 __host__ __device__ constexpr uint32_t persist_words(bool defer) {
   return defer ? (kDeferFields - 1u) * kDeferCap + 2u * kDeferSet + 64u : kDeferSet;
 }

@@ -18,6 +18,7 @@ run sq2 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_I
 run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE GRBM_GUI_ACTIVE
+run mix SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FLOPS_FP32
 python3 tools/pmc_summary.py $OUT/pmc_fused > $OUT/pmc_fused_summary.txt
 # 3. section counters and time shares of the profiling build
 timeout -k 10 200 python3 tools/sections.py 512 > $OUT/sections_fused.txt 2>&1

@@ -86,13 +86,23 @@ bench.py's HIP-event average for the fused kernel in the same run: {r['avg_launc
 
     # static issue cost of the fused kernel's instruction mix
     isa = subprocess.run([sys.executable, "tools/isa_cost.py", "rust-pathtracer_amd/build/pt_kernels.s",
-                          "_ZN2pt16k_bounce_persistILb0ELb0ELb1E", "12"], capture_output=True, text=True, check=True).stdout
+                          "_ZN2pt16k_bounce_persistILb0ELb0ELb1ELb0E", "12"], capture_output=True, text=True, check=True).stdout
     open("profiles/r03_isa_cost_fused.txt", "w").write(isa)
-    issue_cost = float(re.search(r"([\d.]+) cycles per VALU instruction", isa).group(1))
+    issue_cost_static = float(re.search(r"([\d.]+) cycles per VALU instruction", isa).group(1))
 
     tot = counters(rd("pmc_fused_summary.txt"), "k_bounce_persist")
     fetch, write = tot["FETCH_SIZE"][1], tot["WRITE_SIZE"][1]
     rays_per_step = final["roofline"]["rays_per_launch"] * final["roofline"]["launches"] / final["steps"]
+    # the mix of vector instructions as the counters saw it (wave instructions), priced with the per-class issue costs
+    # of tools/valu_ops.hip: add/mul/fma 2.4, transcendental 8.2, conversions 4.2, integer 3.3 (adds and logic 2.4,
+    # shifts and multiplies 4.2), the rest -- compares, selects, min/max, moves -- 3.9
+    valu = tot["SQ_INSTS_VALU"][0]
+    mix = {k: tot["SQ_INSTS_VALU_" + k][0] for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT")}
+    fma_class = mix["ADD_F32"] + mix["MUL_F32"] + mix["FMA_F32"]
+    rest = valu - fma_class - mix["TRANS_F32"] - mix["INT32"] - mix["CVT"]
+    issue_cost = (2.4 * fma_class + 8.2 * mix["TRANS_F32"] + 3.3 * mix["INT32"] + 4.2 * mix["CVT"] + 3.9 * rest) / valu
+    lane_util = tot["SQ_THREAD_CYCLES_VALU"][0] / valu / 64
+    flops = tot["SQ_INSTS_VALU_FLOPS_FP32"][0] * 64 / rays_per_step  # the counter counts per wave instruction
     json.dump({"fused": {
         "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
         "fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write,
@@ -100,11 +110,14 @@ bench.py's HIP-event average for the fused kernel in the same run: {r['avg_launc
         "workload": f"cornell_1920x1080_1024spp_depth32_converge, {tot['FETCH_SIZE'][2]} launches of k_bounce_persist (one per step)",
         # SIMD cycles that went by per VALU wave-instruction issued (GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs)
         "simd_cycles_per_valu_inst": 1024 * (tot["GRBM_GUI_ACTIVE"][0] / 8) / tot["SQ_INSTS_VALU"][0],
-        # what the kernel's instruction mix costs to issue, unweighted over the kernel's text (tools/isa_cost.py with
-        # the per-opcode costs tools/valu_ops.hip measured: 2.4 / 4.2 / 8.2 cycles)
         "issue_cost_cycles_per_valu_inst": issue_cost,
-        "valu_lane_utilisation": tot["SQ_THREAD_CYCLES_VALU"][0] / tot["SQ_INSTS_VALU"][0] / 64,
-        "valu_insts_per_ray": tot["SQ_INSTS_VALU"][0] / rays_per_step,
+        "issue_cost_static_cycles_per_valu_inst": issue_cost_static,
+        "valu_mix": {"fma_add_mul_f32": fma_class / valu, "transcendental_f32": mix["TRANS_F32"] / valu,
+                     "int32": mix["INT32"] / valu, "convert": mix["CVT"] / valu, "other": rest / valu},
+        "fp32_flops_issued_per_ray": flops,
+        "fp32_flops_on_active_lanes_per_ray": flops * lane_util,
+        "valu_lane_utilisation": lane_util,
+        "valu_insts_per_ray": valu / rays_per_step,
         "collected": "round 3, tools/r03_collect.sh on the build of this commit's parent; replayed by bench.py, not measured in its run",
         "source": "profiles/r03_pmc_fused.txt (rocprofv3 --pmc, one pass per counter group), profiles/r03_isa_cost_fused.txt"}},
         open("profiles/pmc_traffic.json", "w"), indent=1)
