@@ -942,19 +942,29 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_defer(RenderPar
 // run at one lane in 64 where a launch of k_bounce_defer does them for 64 slots at once (+3.3 % vector instructions
 // measured, against 6.3 % fewer loop iterations).  With shadow rays in place the one launch is 4 % faster than launch
 // after launch at 1024 samples a pixel (324.7 against 338.1 ms), with the queue 1-3 % (more on short renders, whose
-// launches are all head and tail); slots of an adaptive round's 8 or 16 samples would refill every few iterations,
-// and a slot that is picked up again has its state to load, one lane's trip to memory that the wave waits for, so
-// adaptive renders stay with k_bounce.
+// launches are all head and tail).  The rounds of an adaptive render pick slots up again: their stored state is
+// fetched 32 slots at a time into LDS (the stash, below) -- fetched by the lane that takes the slot, one lane's trip
+// to memory that the whole wave waits for, the one launch gained nothing there (345.6 against 345.8 ms); with the
+// stash it is 3.6 % faster than launch after launch (335.0 against 347.1 ms at threshold 0.01), short rounds of 8
+// samples a slot included.  (Sized for 64 slots at a time the stash took the fourth block off the CU: 387 ms.)
 //
-// RenderParams::fresh_queue: every slot of the queue is untouched (a fixed-count render's only launch): nothing is
-// loaded for it.  RenderParams::last_pass: no slot will run again after this launch: only its totals are written.
+// RenderParams::fresh_queue: every slot of the queue is untouched (a fixed-count render's only launch):
+// nothing is loaded for it.  RenderParams::last_pass: no slot will run again after this launch: only its totals are
+// written.  Renders with a noise test keep the sum of squared samples beside the sum, both in LDS while the slot
+// has a lane.
 
 constexpr uint32_t kPersistGrab = 64;  // queue entries a wave takes from the shared counter at a time
 // per wave: finished-sample sums; DEFER: the shadow queue (owner and origin share a word: 11 fields), credits,
 // finished-sample sums, last-entry marks
 __host__ __device__ constexpr uint32_t persist_words(bool defer) {
-  return defer ? (kDeferFields - 1u) * kDeferCap + 2u * kDeferSet + 64u : kDeferSet;
+  return defer ? (kDeferFields - 1u) * kDeferCap + 2u * kDeferSet + 64u : 2u * kDeferSet;
 }
+// Queues whose slots have been worked on before (the rounds of an adaptive render, a staged render's tail): a wave
+// fetches the stored state of the 64 entries it takes from the queue at once, every lane one entry, into LDS --
+// six 16-byte words and the slot id per entry -- and a lane that takes a slot later reads it from there: one trip
+// to memory per 64 slots for the wave to wait for, not one per slot.
+constexpr uint32_t kStashEntries = 32;  // (such queues are taken 32 entries at a time: 64 would cost the fourth block per CU)
+constexpr uint32_t kStashWords = kStashEntries * (6u * 4u + 1u);
 constexpr uint32_t kPersistOriginBits = 26;  // a shadow ray's origin primitive (+1) beside its owner lane in one word
 
 template <bool GUIDED, bool TRAIN, bool LDS_SCENE, bool DEFER>
@@ -980,10 +990,15 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   float* late = dq + (kDeferFields - 1u) * kDeferCap;                       // [3][64]: credits of the lane's slot
   float* done_sum = DEFER ? late + kDeferSet : dq;                          // [3][64]: its finished samples
   uint32_t* last_entry = reinterpret_cast<uint32_t*>(done_sum + kDeferSet); // [64]: 1 + position of its last queued ray
+  float* sq_sum = done_sum + kDeferSet;  // !DEFER, renders with a noise test: [3][64] the slot's sum of squared samples
   const ShadeParams sp = shade_params(p);
   uint32_t rays_rad = 0, rays_sh = 0, captured = 0;
   const bool fresh = p.fresh_queue != 0, last_pass = p.last_pass != 0;
   const float* cam_lds = stage_camera(p, reinterpret_cast<float*>(lds_free) + (size_t)(blockDim.x >> 6) * persist_words(DEFER));
+  // the stash of fetched slot state (queues that are not fresh), behind the camera: [6][64] q4 and [64] slot ids per wave
+  q4* stash = reinterpret_cast<q4*>(const_cast<float*>(cam_lds) + kCamLdsBytes / sizeof(float)) + (size_t)(threadIdx.x >> 6) * (kStashWords / 4u);
+  uint32_t* stash_px = reinterpret_cast<uint32_t*>(stash + 6u * kStashEntries);
+  const uint32_t grab = fresh ? kPersistGrab : kStashEntries;
 
   auto trace_deferred = [&](uint32_t e) {
     const f3 o = mk3(dq[0 * kDeferCap + e], dq[1 * kDeferCap + e], dq[2 * kDeferCap + e]);
@@ -1020,9 +1035,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
     last_entry[lane] = 0u;
   }
   done_sum[lane] = 0.0f; done_sum[64u + lane] = 0.0f; done_sum[128u + lane] = 0.0f;
+  const bool squares = !DEFER && p.acc2 != nullptr;
+  if (squares) { sq_sum[lane] = 0.0f; sq_sum[64u + lane] = 0.0f; sq_sum[128u + lane] = 0.0f; }
   // the same on every lane of the wave
   uint32_t head = 0, waiting = 0, queued_total = 0, traced_total = 0;  // the LDS queue
-  uint32_t grab_pos = 0, grab_end = 0;                                  // the stretch of the slot queue the wave holds
+  uint32_t grab_pos = 0, grab_end = 0, grab_base = 0;                   // the stretch of the slot queue the wave holds
   bool more = n > 0u;                                                   // the shared counter has not run past the queue yet
   PT_TIC(t_loop);
   for (;;) {
@@ -1043,6 +1060,10 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
       }
       p.acc[pixel] = acc;
       done_sum[lane] = 0.0f; done_sum[64u + lane] = 0.0f; done_sum[128u + lane] = 0.0f;
+      if (squares) {
+        p.acc2[pixel] = q4{sq_sum[lane], sq_sum[64u + lane], sq_sum[128u + lane], 0.0f};
+        sq_sum[lane] = 0.0f; sq_sum[64u + lane] = 0.0f; sq_sum[128u + lane] = 0.0f;
+      }
       if (!last_pass) store_state(p, pixel, ps);
       p.started[pixel] = local;
       has_slot = false;
@@ -1054,27 +1075,55 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
       while (need != 0ull && (grab_pos < grab_end || more)) {
         if (grab_pos == grab_end) {  // a new stretch from the counter all waves share
           uint32_t b = 0u;
-          if (lane == 0u) b = atomicAdd(&p.counters[CNT_GRAB], kPersistGrab);
+          if (lane == 0u) b = atomicAdd(&p.counters[CNT_GRAB], grab);
           b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
           if (b >= n) { more = false; break; }
-          grab_pos = b;
-          grab_end = b + kPersistGrab < n ? b + kPersistGrab : n;
+          grab_pos = grab_base = b;
+          grab_end = b + grab < n ? b + grab : n;
+          if (!fresh) {
+            if (b + lane < grab_end) {
+              const uint32_t px = q_in[b + lane];
+              stash_px[lane] = px;
+              stash[lane] = p.st_o[px];
+              stash[kStashEntries + lane] = p.st_d[px];
+              stash[2u * kStashEntries + lane] = p.st_s[px];
+              const u4 m = p.st_m[px];
+              stash[3u * kStashEntries + lane] = q4{u2f(m.x), u2f(m.y), u2f(m.z), u2f(m.w)};
+              q4 a = p.acc[px];
+              a.w = u2f((uint32_t)p.started[px]);
+              stash[4u * kStashEntries + lane] = a;
+              if (squares) stash[5u * kStashEntries + lane] = p.acc2[px];
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
         }
         const uint32_t n_need = (uint32_t)__popcll(need), room = grab_end - grab_pos;
         const uint32_t take = n_need < room ? n_need : room;
         const uint32_t rank = (uint32_t)__popcll(need & lanes_below);
         if (!has_slot && rank < take) {
-          pixel = q_in[grab_pos + rank];
           if (fresh) {  // an untouched slot: no samples started, no path under way
+            pixel = q_in[grab_pos + rank];
             ps.flags = 0u;
             ps.seed = 0;
             local = 0;
-          } else {
-            ps = load_state(p, pixel);
-            local = p.started[pixel];
+          } else {  // what the wave fetched when it took this stretch of the queue
+            const uint32_t e = grab_pos + rank - grab_base;
+            pixel = stash_px[e];
+            const q4 so = stash[e], sd = stash[kStashEntries + e], ss = stash[2u * kStashEntries + e], sm = stash[3u * kStashEntries + e], sa = stash[4u * kStashEntries + e];
+            ps.o = mk3(so.x, so.y, so.z);
+            ps.d = mk3(sd.x, sd.y, sd.z);
+            ps.sum = mk3(ss.x, ss.y, ss.z);
+            ps.T = mk3(so.w, sd.w, ss.w);
+            ps.seed = ((uint64_t)f2u(sm.y) << 32) | (uint64_t)f2u(sm.x);
+            ps.prev_pdf = sm.z;
+            ps.flags = f2u(sm.w);
+            local = (int)f2u(sa.w);
             if (!DEFER) {
-              const q4 a = p.acc[pixel];
-              done_sum[lane] = a.x; done_sum[64u + lane] = a.y; done_sum[128u + lane] = a.z;
+              done_sum[lane] = sa.x; done_sum[64u + lane] = sa.y; done_sum[128u + lane] = sa.z;
+              if (squares) {
+                const q4 sb = stash[5u * kStashEntries + e];
+                sq_sum[lane] = sb.x; sq_sum[64u + lane] = sb.y; sq_sum[128u + lane] = sb.z;
+              }
             }
           }
           sl = decode_slot(p, pixel);
@@ -1098,6 +1147,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
       PT_PROF(PF_REGEN);
       if (ps.flags & kFoldPending) {  // a sample just ended: fold it into the slot's sum
         done_sum[lane] += ps.sum.x; done_sum[64u + lane] += ps.sum.y; done_sum[128u + lane] += ps.sum.z;
+        if (squares) {
+          q4 b = q4{sq_sum[lane], sq_sum[64u + lane], sq_sum[128u + lane], 0.0f};
+          add_squares(b, ps.sum);
+          sq_sum[lane] = b.x; sq_sum[64u + lane] = b.y; sq_sum[128u + lane] = b.z;
+        }
         ps.flags &= ~kFoldPending;
       }
       if (local >= sl.count) {
@@ -1428,31 +1482,35 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, Que
   else launch_bounce_t<false, false>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
   PT_KCHECK();
 }
+// (fresh_queue is read at run time: a variant compiled for queues that are not fresh ran adaptive renders 4 % slower,
+// 349 against 335 ms, and one compiled for fresh queues changed nothing)
+template <bool GUIDED, bool TRAIN, bool LDS_SCENE, bool DEFER>
+static void launch_persist_f(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c, size_t lds) {
+  k_bounce_persist<GUIDED, TRAIN, LDS_SCENE, DEFER><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+}
 template <bool GUIDED, bool TRAIN>
 static void launch_persist_t(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c, bool lds_scene, bool defer, size_t lds) {
   if (defer) {
-    if (lds_scene) k_bounce_persist<GUIDED, TRAIN, true, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
-    else k_bounce_persist<GUIDED, TRAIN, false, true><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+    if (lds_scene) launch_persist_f<GUIDED, TRAIN, true, true>(p, qin, cnt_in, c, lds);
+    else launch_persist_f<GUIDED, TRAIN, false, true>(p, qin, cnt_in, c, lds);
   } else {
-    if (lds_scene) k_bounce_persist<GUIDED, TRAIN, true, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
-    else k_bounce_persist<GUIDED, TRAIN, false, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+    if (lds_scene) launch_persist_f<GUIDED, TRAIN, true, false>(p, qin, cnt_in, c, lds);
+    else launch_persist_f<GUIDED, TRAIN, false, false>(p, qin, cnt_in, c, lds);
   }
 }
 // The deferred form: a shadow ray's origin primitive shares a word with its owner lane, which bounds the triangle
 // count; beyond it shadow rays are traced in place.
 static bool persist_defers(const RenderParams& p) {
-  return p.defer_shadow && p.scene.num_tris < (1u << kPersistOriginBits) - 1u;
+  return p.defer_shadow && !p.acc2 && p.scene.num_tris < (1u << kPersistOriginBits) - 1u;
 }
-// k_bounce_persist keeps no per-sample sums: renders that need them (adaptive) go launch after launch.  A form
-// that kept them was measured on the long rounds of an adaptive render (32 samples per slot and more) and gained
-// nothing, 345.6 against 345.8 ms: a slot that is picked up again has its state to load when a lane takes it,
-// one lane's trip to memory that the whole wave waits for.
-bool bounce_persist_usable(const RenderParams& p) { return !p.acc2; }
+// (every render the fused kernels take: kept as the one place to say otherwise)
+bool bounce_persist_usable(const RenderParams&) { return true; }
 static size_t persist_lds_bytes(const RenderParams& p, int threads, bool& lds_scene) {
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
   lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
   return (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) +
-         (size_t)(threads / 64) * persist_words(persist_defers(p)) * sizeof(float) + kCamLdsBytes;
+         (size_t)(threads / 64) * persist_words(persist_defers(p)) * sizeof(float) + kCamLdsBytes +
+         (p.fresh_queue ? 0u : (size_t)(threads / 64) * kStashWords * sizeof(float));
 }
 // The whole of queue qin (its length in counters[cnt_in]) in one launch; counters[CNT_GRAB] must be zero.
 void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c) {

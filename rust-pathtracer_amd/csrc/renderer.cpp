@@ -1555,6 +1555,7 @@ int pt_dbg_fused_occupancy(int adaptive, unsigned long long* lds_bytes) {
   HIP_CHECK(hipSetDevice(s.device));
   RenderParams p = make_params(s, 0, 64, 32, 1, false, false);
   if (adaptive) p.acc2 = reinterpret_cast<q4*>(s.st_o);  // only tested for being set
+  else p.fresh_queue = 1;                                 // a fixed-count render starts from untouched slots
   size_t lds = 0;
   const int n = bounce_occupancy(p, 256, &lds, g_one_launch != 0);
   if (lds_bytes) *lds_bytes = lds;
