@@ -286,6 +286,11 @@ int max_chunks_for(size_t px) {
   return (int)std::max<size_t>(1, std::min<size_t>(16, target_slots / std::max<size_t>(px, 1)));
 }
 
+// Slots per pixel an adaptive render of a scene that runs fused may take: 16 M slots (1080p: 8 chunks, of 4 samples
+// each in a round of 32; 4 / 8 / 16 chunks at threshold 0.01: 334.3 / 327.9 / 330.2 ms -- shorter slots shorten the
+// end of every round, where waves run on with a few lanes, until refilling costs more than that).
+int adaptive_room(size_t px) { return (int)std::max<size_t>(1, std::min<size_t>(16, ((size_t)16u << 20) / std::max<size_t>(px, 1))); }
+
 // The per-slot arrays for `chunks` slots per pixel (whatever they held is gone).
 constexpr size_t kSlotBytes = 9 * 16 + 5 * 4;  // nine 16-byte words, started, hit_inst and three queue entries
 void alloc_slots(State& s, int chunks) {
@@ -747,7 +752,7 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
     // not of what earlier renders left allocated, so a render gives the same result whatever came before it
     const bool staged_scene = !s.borrowed && staged_by_default(s);
     const int room = staged_scene ? (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)144 << 20) / std::max<uint32_t>(npx, 1u)))
-                                  : s.base_chunks;
+                                  : (s.borrowed ? s.base_chunks : adaptive_room(npx));
     const int least = staged_scene ? 1 : 4;  // samples a chunk takes per round, at least
     const int cap = g_adaptive_chunks > 0 ? std::min(g_adaptive_chunks, room) : room;
     const int step = local_target(std::min(round, total)), start = local_target(std::min(first, total));
