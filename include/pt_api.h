@@ -140,7 +140,7 @@ PT_EXPORT void pt_set_adaptive_round(int samples);
 PT_EXPORT int  pt_get_adaptive_round(void);
 /* Adaptive renders split a pixel's samples into several chunks rendered side by side (own random stream
  * each, like the ranks of a sharded render) where that keeps enough paths in flight; every chunk takes the
- * same number of samples per round.  0 (default): as many as the renderer has room for, a power of two that
+ * same number of samples per round.  0 (default): as many as 16 M slots allow (8 at 1920x1080), a power of two that
  * divides the round and leaves every chunk at least 4 samples of it (scenes that run staged by default: up to 64,
  * at least 1 sample; see pt_last_render_chunks); 1: one stream per pixel, the sample sequence of the reference's
  * launch loop.  Env: PT_ADAPTIVE_CHUNKS. */
@@ -157,9 +157,10 @@ PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
  * needs per-sample sums). */
 PT_EXPORT void pt_set_defer_shadow(int on);
 PT_EXPORT int  pt_get_defer_shadow(void);
-/* Fused pipeline, renders with a fixed sample count.  on (default, env PT_PERSIST=1): the whole render is one
+/* Fused pipeline.  on (default, env PT_PERSIST=1): a fixed-count render, or a round of an adaptive one, is one
  * kernel launch; its waves take slots from a shared counter and a lane that has finished a slot takes the next
- * one, so no path state goes through memory (4 % faster at 1024 samples a pixel than launch after launch).
+ * one, so no path state goes through memory in a fixed-count render (4 % faster at 1024 samples a pixel than launch
+ * after launch) and a round's stored slot state is fetched 32 slots at a time into LDS (adaptive renders 5 % faster).
  * off: launch after launch, 32 bounces of every slot each.  The same paths and, with shadow rays traced in place,
  * the same bits either way. */
 PT_EXPORT void pt_set_one_launch(int on);
