@@ -917,9 +917,26 @@ def test_pipelines_agree_and_are_deterministic(gpu):
                             first = (img, big)
                         else:
                             assert np.array_equal(img, first[0]) and np.array_equal(big, first[1])
+        # adaptive renders: every round is one launch that picks the slots up where the last round left them (state
+        # fetched 32 slots at a time into LDS) -- the bits and per-pixel counts of the staged kernels and of the fused
+        # kernel launch after launch, with one stream per pixel and with several chunks
+        L.pt_set_defer_shadow(DEFER_DEFAULT)
+        for chunks in (1, 0):
+            L.pt_set_adaptive_chunks(chunks)
+            results = []
+            for pipeline, one_launch in ((0, 1), (1, 1), (1, 0)):
+                L.pt_set_pipeline(pipeline)
+                L.pt_set_one_launch(one_launch)
+                L.pt_set_frame(4)
+                img = gpu.render_rgb(200, 120, 256, noise_threshold=1.5, min_adaptive_samples=32)
+                results.append((img, gpu.sample_counts(200, 120)[0]))
+            assert len(np.unique(results[0][1])) > 2  # it adapts
+            for img, counts in results[1:]:
+                assert np.array_equal(img, results[0][0]) and np.array_equal(counts, results[0][1])
     finally:
         L.pt_set_pipeline(1)
         L.pt_set_one_launch(1)
+        L.pt_set_adaptive_chunks(0)
         L.pt_set_defer_shadow(DEFER_DEFAULT)
 
 
