@@ -424,6 +424,37 @@ PT_HD Hit trace_ray(const SceneView& sc, f3 o, f3 d, float tmin, float tmax, boo
   return hit;
 }
 
+// trace_ray for a wide tree that is one node (up to 16 leaf slots and 24 items: the reference's scene is one): what
+// trace_ray does for such a tree -- the same slab test, the same item tests in the same order, the same hit -- without
+// what it carries for trees in general (the loop over nodes with its stack, the child ranks, the order of internal
+// children): about 35 vector instructions and half a dozen registers less per query.
+PT_HD Hit trace_ray_one_node(const SceneView& sc, f3 o, f3 d, float tmax, bool any_hit, uint32_t origin) {
+  Hit hit{-1, tmax, 0.f, 0.f};
+  RayWide rw;
+  rw.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  rw.oi = mk3(-o.x * rw.idir.x, -o.y * rw.idir.y, -o.z * rw.idir.z);
+  rw.octinv = (d.x < 0.0f ? 0u : 4u) | (d.y < 0.0f ? 0u : 2u) | (d.z < 0.0f ? 0u : 1u);
+  const float rmag = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.vmag;
+  const u4* n = sc.wide;
+  uint32_t bits = intersect_children_wide(n, rw, 0.0f, tmax, sc.wide_groups) & 0x00ffffffu;
+  if (origin) bits &= ~sc.home_wide[2u * (origin - 1u) + 1u];  // every primitive's home is this node
+  const uint32_t base = n[0].x >> 8;
+  while (bits) {
+    PT_PROF(any_hit ? PF_SH_TRI : PF_TRI);
+    const int ti = __builtin_ctz(bits);
+    bits &= bits - 1u;
+    const q4* tp = sc.tris + (uint32_t)kTriWords * (base + (uint32_t)ti);
+    const q4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+    int res = fast_triangle(q0, q1, q2, q3, o, d, rmag, 0.0f, hit);
+    if (res == 2) {
+      PT_PROF(PF_FALLBACK);
+      res = watertight_item(sc, q1, q2, q3, o, d, 0.0f, hit) ? 1 : 0;
+    }
+    if (res == 1 && any_hit) return hit;
+  }
+  return hit;
+}
+
 // The same traversal as trace_ray, cut into single steps so that a kernel can interleave rays: a lane
 // whose ray has finished takes the next ray while its neighbours are still traversing theirs.
 // A ray is in one of three states: triangles of a visited node wait to be tested (wants_tri), child

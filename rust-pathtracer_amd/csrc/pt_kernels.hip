@@ -967,8 +967,10 @@ constexpr uint32_t kStashEntries = 32;  // (such queues are taken 32 entries at 
 constexpr uint32_t kStashWords = kStashEntries * (6u * 4u + 1u);
 constexpr uint32_t kPersistOriginBits = 26;  // a shadow ray's origin primitive (+1) beside its owner lane in one word
 
-template <bool GUIDED, bool TRAIN, bool LDS_SCENE, bool DEFER>
+// SCENE: 0 the packed tree in device memory, 1 the wide tree in LDS, 2 the same when it is one node (trace_ray_one_node)
+template <bool GUIDED, bool TRAIN, int SCENE, bool DEFER>
 __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderParams p, int qin, int cnt_in) {
+  constexpr bool LDS_SCENE = SCENE != 0;
   const uint32_t n = p.counters[cnt_in];
   const uint32_t* q_in = p.queue[qin];
   LdsStack st = lds_stack();
@@ -1000,6 +1002,13 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   uint32_t* stash_px = reinterpret_cast<uint32_t*>(stash + 6u * kStashEntries);
   const uint32_t grab = fresh ? kPersistGrab : kStashEntries;
 
+  auto trace = [&](f3 o, f3 d, float tmax, bool any_hit, uint32_t origin) -> Hit {
+    if (SCENE == 2) {
+      if (!any_hit) { PT_PROF(PF_NODE); } else { PT_PROF(PF_SH_NODE); }
+      return trace_ray_one_node(sc, o, d, tmax, any_hit, origin);
+    }
+    return trace_ray(sc, o, d, 0.0f, tmax, any_hit, st, p.stack_depth, origin);
+  };
   auto trace_deferred = [&](uint32_t e) {
     const f3 o = mk3(dq[0 * kDeferCap + e], dq[1 * kDeferCap + e], dq[2 * kDeferCap + e]);
     const f3 d = mk3(dq[3 * kDeferCap + e], dq[4 * kDeferCap + e], dq[5 * kDeferCap + e]);
@@ -1008,7 +1017,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
     rays_sh++;
     PT_PROF(PF_SHADOW);
     PT_TIC(t_sh);
-    const Hit h = trace_ray(sc, o, d, 0.0f, tmax, true, st, p.stack_depth, word & ((1u << kPersistOriginBits) - 1u));
+    const Hit h = trace(o, d, tmax, true, word & ((1u << kPersistOriginBits) - 1u));
     if (h.prim < 0) {
       const uint32_t owner = word >> kPersistOriginBits;
       atomicAdd(&late[owner], dq[8 * kDeferCap + e]);
@@ -1165,7 +1174,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
     if (active && !retiring) {
       rc.s = hash_sample_index(p, sl, local - 1);
       PT_TIC(t_trace);
-      const Hit h = trace_ray(sc, ps.o, ps.d, 0.0f, 1e16f, false, st, p.stack_depth, ps.origin);
+      const Hit h = trace(ps.o, ps.d, 1e16f, false, ps.origin);
       PT_TOC(t_trace, PT_T_TRACE);
       rays_rad++;
       TrainVertex tv;
@@ -1176,7 +1185,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
       if (!DEFER && sr.valid) {
         PT_PROF(PF_SHADOW);
         rays_sh++;
-        const Hit o = trace_ray(sc, sr.o, sr.d, 0.0f, sr.tmax, true, st, p.stack_depth, sr.origin);
+        const Hit o = trace(sr.o, sr.d, sr.tmax, true, sr.origin);
         if (o.prim < 0) ps.sum += sr.contrib;
       }
     }
@@ -1484,18 +1493,22 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, Que
 }
 // (fresh_queue is read at run time: a variant compiled for queues that are not fresh ran adaptive renders 4 % slower,
 // 349 against 335 ms, and one compiled for fresh queues changed nothing)
-template <bool GUIDED, bool TRAIN, bool LDS_SCENE, bool DEFER>
+template <bool GUIDED, bool TRAIN, int SCENE, bool DEFER>
 static void launch_persist_f(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c, size_t lds) {
-  k_bounce_persist<GUIDED, TRAIN, LDS_SCENE, DEFER><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
+  k_bounce_persist<GUIDED, TRAIN, SCENE, DEFER><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, cnt_in);
 }
 template <bool GUIDED, bool TRAIN>
 static void launch_persist_t(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c, bool lds_scene, bool defer, size_t lds) {
+  static const bool one_node_env = !(getenv("PT_ONE_NODE") && atoi(getenv("PT_ONE_NODE")) == 0);
+  const bool one_node = lds_scene && p.scene.wide_one_node != 0u && one_node_env;
   if (defer) {
-    if (lds_scene) launch_persist_f<GUIDED, TRAIN, true, true>(p, qin, cnt_in, c, lds);
-    else launch_persist_f<GUIDED, TRAIN, false, true>(p, qin, cnt_in, c, lds);
+    if (one_node) launch_persist_f<GUIDED, TRAIN, 2, true>(p, qin, cnt_in, c, lds);
+    else if (lds_scene) launch_persist_f<GUIDED, TRAIN, 1, true>(p, qin, cnt_in, c, lds);
+    else launch_persist_f<GUIDED, TRAIN, 0, true>(p, qin, cnt_in, c, lds);
   } else {
-    if (lds_scene) launch_persist_f<GUIDED, TRAIN, true, false>(p, qin, cnt_in, c, lds);
-    else launch_persist_f<GUIDED, TRAIN, false, false>(p, qin, cnt_in, c, lds);
+    if (one_node) launch_persist_f<GUIDED, TRAIN, 2, false>(p, qin, cnt_in, c, lds);
+    else if (lds_scene) launch_persist_f<GUIDED, TRAIN, 1, false>(p, qin, cnt_in, c, lds);
+    else launch_persist_f<GUIDED, TRAIN, 0, false>(p, qin, cnt_in, c, lds);
   }
 }
 // The deferred form: a shadow ray's origin primitive shares a word with its owner lane, which bounds the triangle
@@ -1534,11 +1547,11 @@ int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out, bool o
     int n = 0;
     hipError_t e;
     if (persist_defers(p))
-      e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, true, true>, threads, lds)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, false, true>, threads, lds);
+      e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, 1, true>, threads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, 0, true>, threads, lds);
     else
-      e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, true, false>, threads, lds)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, false, false>, threads, lds);
+      e = lds_scene ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, 1, false>, threads, lds)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, 0, false>, threads, lds);
     return e == hipSuccess ? n : -1;
   }
   const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);

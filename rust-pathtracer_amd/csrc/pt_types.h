@@ -269,6 +269,7 @@ struct SceneView {
   const u4* wide_src;
   const uint32_t* home_wide;
   uint32_t wide_groups;      // slot groups to test per wide node: the most any node of the tree uses
+  uint32_t wide_one_node;    // the wide tree is its root alone (every leaf slot in one node)
   // 4 x q4 per leaf item (a triangle, or two forming a parallelogram) in BVH leaf order (see the record
   // layout in pt_bvh.h): v0 and the rows that map (p - v0) to the barycentrics of v1, v2 and to the distance
   // from the plane

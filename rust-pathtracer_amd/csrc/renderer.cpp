@@ -214,6 +214,7 @@ void upload_scene(State& s) {
   s.scene.wide_src = bvh.wide_nodes.empty() ? nullptr : s.d_wide;
   s.scene.home_wide = bvh.wide_nodes.empty() ? nullptr : s.d_home_wide;
   s.scene.wide_groups = bvh.wide_groups;
+  s.scene.wide_one_node = (!bvh.wide_nodes.empty() && bvh.wide_depth == 1) ? 1u : 0u;
   s.scene.nodes = s.d_nodes;
   s.scene.tris = s.d_tris;
   s.scene.shade = s.d_shade;
@@ -1393,6 +1394,7 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
     s.scene.wide_src = bvh.wide_nodes.empty() ? nullptr : dw;
     s.scene.home_wide = bvh.wide_nodes.empty() ? nullptr : dh;
     s.scene.wide_groups = bvh.wide_groups;
+  s.scene.wide_one_node = (!bvh.wide_nodes.empty() && bvh.wide_depth == 1) ? 1u : 0u;
     s.scene.nodes = dn;
     s.scene.tris = dt;
     s.scene.shade = ds;

@@ -86,7 +86,7 @@ bench.py's HIP-event average for the fused kernel in the same run: {r['avg_launc
 
     # static issue cost of the fused kernel's instruction mix
     isa = subprocess.run([sys.executable, "tools/isa_cost.py", "rust-pathtracer_amd/build/pt_kernels.s",
-                          "_ZN2pt16k_bounce_persistILb0ELb0ELb1ELb0E", "12"], capture_output=True, text=True, check=True).stdout
+                          "_ZN2pt16k_bounce_persistILb0ELb0ELi2ELb0E", "12"], capture_output=True, text=True, check=True).stdout
     open("profiles/r03_isa_cost_fused.txt", "w").write(isa)
     issue_cost_static = float(re.search(r"([\d.]+) cycles per VALU instruction", isa).group(1))
 
