@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   auto trace = [&](f3 o, f3 d, float tmax, bool any_hit, uint32_t origin) -> Hit {
     if (SCENE == 2) {
       if (!any_hit) { PT_PROF(PF_NODE); } else { PT_PROF(PF_SH_NODE); }
-      return trace_ray_one_node(sc, o, d, tmax, any_hit, origin);
+      return trace_ray_one_node(sc, o, d, tmax, any_hit, origin, !any_hit);  // radiance rays start with tmax 1e16
     }
     return trace_ray(sc, o, d, 0.0f, tmax, any_hit, st, p.stack_depth, origin);
   };
