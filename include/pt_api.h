@@ -148,13 +148,13 @@ PT_EXPORT void pt_set_adaptive_chunks(int chunks);
 PT_EXPORT int  pt_get_adaptive_chunks(void);
 PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
 
-/* Fused pipeline only.  off (default, env PT_DEFER_SHADOW=0): shadow rays are traced where they are made, a slot's
- * samples are added in sample order, and the fused and the staged pipeline agree bit for bit.  on: each wave queues
- * its shadow rays in LDS and traces them 64 at a time, at full occupancy of the wave; a slot's total is the same
- * set of terms added in a different order, so images agree with the staged pipeline to rounding (same paths).
- * The queue was worth 12 % when traversal cost half again as much as it does now; on the present kernels it costs
- * 3 % (1080p, 1024 spp: 325 ms in place, 335 ms queued).  Adaptive renders always trace in place (the noise test
- * needs per-sample sums). */
+/* Fused pipeline only.  0 (env PT_DEFER_SHADOW=0): shadow rays are traced where they are made, a slot's samples are
+ * added in sample order, and the fused and the staged pipeline agree bit for bit.  1: each wave queues its shadow
+ * rays in LDS and traces them 64 at a time, at full occupancy of the wave; a slot's total is the same set of terms
+ * added in a different order, so images agree with the staged pipeline to rounding (same paths).  -1 (default):
+ * chosen per scene -- queued for trees of more than one node and up to 1024 triangles, where it measures 10 %
+ * faster, in place otherwise (the reference's scene: 298 ms in place, 312 ms queued at 1080p, 1024 spp).
+ * Adaptive renders always trace in place (the noise test needs per-sample sums). */
 PT_EXPORT void pt_set_defer_shadow(int on);
 PT_EXPORT int  pt_get_defer_shadow(void);
 /* Fused pipeline.  on (default, env PT_PERSIST=1): a fixed-count render, or a round of an adaptive one, is one

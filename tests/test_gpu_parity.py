@@ -17,7 +17,7 @@ GOLD = os.path.join(HERE, "golden")
 ROOT = os.path.dirname(HERE)
 
 
-DEFER_DEFAULT = 0  # shadow rays are traced in place unless pt_set_defer_shadow(1) / PT_DEFER_SHADOW=1 says otherwise
+DEFER_DEFAULT = -1  # per scene: shadow rays in place for the built-in scene (pt_set_defer_shadow; 0 in place, 1 queued)
 
 def rel_rmse(img, ref):
     """sqrt(mean(((I-R)/(R+0.01))^2)) per the measurement plan."""
@@ -888,7 +888,7 @@ def test_pipelines_agree_and_are_deterministic(gpu):
     With shadow rays queued per wave and traced 64 at a time (pt_set_defer_shadow(1)) the paths and the terms per
     pixel are the same and the order of additions is not: run-to-run identical, equal to rounding."""
     L = gpu.lib()
-    assert L.pt_get_one_launch() == 1 and L.pt_get_defer_shadow() == DEFER_DEFAULT == 0
+    assert L.pt_get_one_launch() == 1 and L.pt_get_defer_shadow() == DEFER_DEFAULT == -1
 
     def render(w, h, spp):
         L.pt_set_frame(4)
@@ -901,6 +901,7 @@ def test_pipelines_agree_and_are_deterministic(gpu):
         staged, rays = render(96, 54, 32)
         staged_big, rays_big = render(1280, 720, 64)  # enough slots that every wave refills many times; two chunks
         L.pt_set_pipeline(1)
+        assert np.array_equal(render(96, 54, 32)[0], staged)  # the default for this scene: shadow rays in place
         for defer in (0, 1):
             L.pt_set_defer_shadow(defer)
             for one_launch in (1, 0):

@@ -15,4 +15,4 @@ for defer in (0, 1):
         rr, rs = gpu.ray_counts()
         ms = L.pt_last_render_ms()
         print(f"defer {defer} thr {thr}: {ms:.1f} ms rounds {r} mean spp {c.mean():.1f} Mrays/s {(rr + rs) / ms / 1e3:.0f} image mean {img.mean():.6f}", flush=True)
-L.pt_set_defer_shadow(0)
+L.pt_set_defer_shadow(-1)

@@ -14,4 +14,4 @@ for defer in (0, 1):
         lds = C.c_uint64(0)
         n = L.pt_dbg_fused_occupancy(adaptive, C.byref(lds))
         print(f"defer {defer} adaptive {adaptive}: {n} blocks per CU, {lds.value} bytes of LDS per block")
-L.pt_set_defer_shadow(0)
+L.pt_set_defer_shadow(-1)
