@@ -28,6 +28,9 @@ if os.environ.get("GUIDED"):  # configuration 3: seeded synthetic field, 8 x 8 x
     L.guiding_set_grid_res(8, 8, 8)
     gpu.upload_snapshot(np.array(regions, np.float32), np.array(lobes, np.float32))
     L.guiding_set_enabled(1)
+if os.environ.get("SPHERES"):  # SPHERES="n subdivisions": that many spheres in the room instead of the built-in scene
+    n_s, sub = (int(a) for a in os.environ["SPHERES"].split())
+    L.pt_scene_synthetic(42, n_s, sub)
 gpu.render_rgb(w, h, spp)
 buf = (C.c_uint64 * 64)()
 n = L.pt_dbg_profile_counters(buf)
