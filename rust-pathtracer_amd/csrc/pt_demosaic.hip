@@ -4,7 +4,7 @@
 // The reference runs six in-place passes over three colour planes.  In every pass a site
 // writes only itself and reads only sites that the pass does not write (or itself, through
 // border clamping, before its own write), so each pass is a data-parallel gather.  The shipped
-// kernel, k_gradient_fused, runs them all on one tile in LDS.  The pass-by-pass form it fuses is kept
+// kernel, k_gradient_tiles, runs them all on one tile in LDS.  The pass-by-pass form it fuses is kept
 // for comparison in builds with -DPT_DEMOSAIC_PASSES (the profiling library) only:
 //   k_green   raw            -> g     (passes 0+1: plane split folded into the reads)
 //   k_rb_at_g raw, g         -> r, b  (pass 2; red/blue sites carry their raw value / 0)
@@ -13,6 +13,7 @@
 // Arithmetic is plain fp32 in the reference's operation order; this file is compiled with
 // FMA contraction off and correctly rounded division so results match bit for bit.
 #include "pt_kernels.h"
+#include "pt_demosaic_tile.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -146,15 +147,23 @@ __global__ void k_combine(const float* r, const float* g, const float* b, float*
 
 // ------------------------------------------------------------------ fused gradient method
 // The four passes above move about 70 bytes per pixel through HBM (three intermediate planes written
-// and read back).  k_gradient_fused runs them on one tile per workgroup with the planes in LDS: raw is
-// read once with a 5-pixel apron, rgb written once (about 20 bytes per pixel).  Every plane value is
-// computed by the same expressions in the same order as in the pass kernels, so the result is the same
-// bits; out-of-image coordinates are clamped before the LDS lookup, exactly as getf() clamps them.
-constexpr int kTW = 64, kTH = 16;              // output tile
-constexpr int kHR = 5, kHG = 3, kHS = 2;       // aprons: raw, green, red/blue planes
+// and read back).  k_gradient_tiles runs them on one tile per workgroup with the planes in LDS: raw is
+// read once with an apron, rgb written once (about 20 bytes per pixel).  Every plane value is computed by
+// the same expressions in the same order as in the pass kernels, so the result is the same bits.
+// Two forms of the tile routine:
+//   border_tile    any tile: coordinates are clamped before every LDS lookup, exactly as getf() clamps them, and
+//                  the colour of a clamped neighbour is looked up where it was clamped to;
+//   interior_tile  a tile whose apron lies inside the image (pt_demosaic_tile.h): nothing is clamped, colours are
+//                  compile-time constants of the pattern, a thread works on a 2x2 cell (no lane idles because its
+//                  site has the wrong colour), neighbours are read as aligned pairs.
+// The grid lists the border tiles first, so that the slower routine runs beside the interior tiles, not after them.
+constexpr int kTW = dm::kTileW, kTH = dm::kTileH;  // output tile
+constexpr int kHR = 5, kHG = 3, kHS = 2;           // aprons of border_tile: raw, green, red/blue planes
 constexpr int kRW = kTW + 2 * kHR, kRH = kTH + 2 * kHR;
 constexpr int kGW = kTW + 2 * kHG, kGH = kTH + 2 * kHG;
 constexpr int kSW = kTW + 2 * kHS, kSH = kTH + 2 * kHS;
+constexpr int kBorderFloats = kRW * kRH + kGW * kGH + 2 * kSW * kSH;
+constexpr int kTileFloats = 4 * dm::kPlane > kBorderFloats ? 4 * dm::kPlane : kBorderFloats;
 
 struct Tile {
   int x0, y0, w, h, pattern;
@@ -178,13 +187,13 @@ struct Tile {
   }
 };
 
-__global__ void __launch_bounds__(256) k_gradient_fused(const float* raw, float* out, int w, int h, int pattern) {
-  __shared__ float s_raw[kRW * kRH];
-  __shared__ float s_g[kGW * kGH];
-  __shared__ float s_r[kSW * kSH];
-  __shared__ float s_b[kSW * kSH];
+__device__ __forceinline__ void border_tile(const float* raw, float* out, int w, int h, int pattern, int x0, int y0, float* lds) {
+  float* s_raw = lds;
+  float* s_g = s_raw + kRW * kRH;
+  float* s_r = s_g + kGW * kGH;
+  float* s_b = s_r + kSW * kSH;
   Tile t;
-  t.x0 = blockIdx.x * kTW; t.y0 = blockIdx.y * kTH; t.w = w; t.h = h; t.pattern = pattern;
+  t.x0 = x0; t.y0 = y0; t.w = w; t.h = h; t.pattern = pattern;
   t.raw = s_raw; t.g = s_g; t.r = s_r; t.b = s_b;
   const int tid = threadIdx.x;
   // mosaic with apron (only in-image cells are ever read)
@@ -287,6 +296,91 @@ __global__ void __launch_bounds__(256) k_gradient_fused(const float* raw, float*
   }
 }
 
+template <int P>
+__device__ __forceinline__ void interior_tile(const float* raw, float* out, int w, int x0, int y0, float* lds) {
+  float* s_raw = lds;
+  float* s_g = lds + dm::kPlane;
+  float* s_rg = lds + 2 * dm::kPlane;
+  float* s_bg = lds + 3 * dm::kPlane;
+  const int tid = threadIdx.x;
+  const bool pairs = (w & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;  // x0, y0 and the cells are even
+  const float* src = raw + (size_t)(y0 - dm::kApron) * (size_t)w + (size_t)(x0 - dm::kApron);
+  {  // a wave takes every fourth row: 64 columns by lane, the last four by its first lanes; all loads issued
+     // before the first is waited for
+    static_assert(dm::kStride == 68 && dm::kRows % 4 == 0, "row split below");
+    constexpr int kPer = dm::kRows / 4;
+    const int lane = tid & 63, first = tid >> 6;
+    const float* row = src + (size_t)first * (size_t)w + lane;
+    float v[kPer], e[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) v[i] = row[(size_t)(4 * i) * (size_t)w];
+    if (lane < 4) {
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) e[i] = row[(size_t)(4 * i) * (size_t)w + 64];
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) s_raw[(first + 4 * i) * dm::kStride + lane] = v[i];
+    if (lane < 4) {
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) s_raw[(first + 4 * i) * dm::kStride + 64 + lane] = e[i];
+    }
+  }
+  __syncthreads();
+  static_assert(dm::kCellsW == 32, "cell index split below");
+  for (int q = tid; q < dm::kCellsW * dm::kCellsH; q += 256)
+    dm::green_cell<P>(s_raw, s_g, (2 + 2 * (q >> 5)) * dm::kStride + 2 + 2 * (q & 31));
+  __syncthreads();
+  for (int q = tid; q < dm::kCellsW * dm::kCellsH; q += 256)
+    dm::chroma_cell<P>(s_raw, s_g, s_rg, s_bg, (2 + 2 * (q >> 5)) * dm::kStride + 2 + 2 * (q & 31));
+  __syncthreads();
+  for (int q = tid; q < dm::kOutCellsW * dm::kOutCellsH; q += 256) {
+    const int qy = q / dm::kOutCellsW, qx = q - qy * dm::kOutCellsW;
+    float row0[6], row1[6];
+    dm::combine_cell(s_g, s_rg, s_bg, (dm::kApron + 2 * qy) * dm::kStride + dm::kApron + 2 * qx, row0, row1);
+    float* o = out + 3 * ((size_t)(y0 + 2 * qy) * (size_t)w + (size_t)(x0 + 2 * qx));
+    if (pairs) {  // both rows start on 8-byte boundaries
+#pragma unroll
+      for (int j = 0; j < 6; j += 2) dm::st2(o + j, row0[j], row0[j + 1]);
+      o += 3 * (size_t)w;
+#pragma unroll
+      for (int j = 0; j < 6; j += 2) dm::st2(o + j, row1[j], row1[j + 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) o[j] = row0[j];
+      o += 3 * (size_t)w;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) o[j] = row1[j];
+    }
+  }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) k_gradient_tiles(const float* raw, float* out, int w, int h, dm::TileGrid tg) {
+  __shared__ __attribute__((aligned(16))) float lds[kTileFloats];
+  int b = (int)blockIdx.x;
+  if (b >= tg.n_edge) {
+    b -= tg.n_edge;
+    const int iw = tg.ix1 - 1, by = b / iw, bx = b - by * iw;
+    interior_tile<P>(raw, out, w, (1 + bx) * kTW, (1 + by) * kTH, lds);
+    return;
+  }
+  // the frame of border tiles: the first row of tiles, the rows from iy1 on, and in between the first column and
+  // the columns from ix1 on
+  int bx, by;
+  const int top = tg.gw, bottom = (tg.gh - tg.iy1) * tg.gw;
+  if (b < top) {
+    bx = b; by = 0;
+  } else if (b < top + bottom) {
+    b -= top;
+    by = tg.iy1 + b / tg.gw; bx = b % tg.gw;
+  } else {
+    b -= top + bottom;
+    const int mw = 1 + tg.gw - tg.ix1, c = b % mw;
+    by = 1 + b / mw; bx = c == 0 ? 0 : tg.ix1 + c - 1;
+  }
+  border_tile(raw, out, w, h, P, bx * kTW, by * kTH, lds);
+}
+
 // src/main.rs:344-401
 __global__ void k_bilinear(const float* raw, float* out, int w, int h, int pattern) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -347,8 +441,14 @@ void launch_demosaic(const float* d_raw, float* d_out, float* d_tmp, int w, int 
   }
 #endif
   (void)d_tmp;
-  const dim3 tiles((unsigned)((w + kTW - 1) / kTW), (unsigned)((h + kTH - 1) / kTH));
-  k_gradient_fused<<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, pattern);
+  const dm::TileGrid tg = dm::tile_grid(w, h);
+  const unsigned tiles = (unsigned)(tg.gw * tg.gh);
+  switch (pattern < 0 ? 0 : (pattern > 3 ? 3 : pattern)) {  // cfa_at clamps the pattern the same way
+    case 0: k_gradient_tiles<0><<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, tg); break;
+    case 1: k_gradient_tiles<1><<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, tg); break;
+    case 2: k_gradient_tiles<2><<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, tg); break;
+    default: k_gradient_tiles<3><<<tiles, 256, 0, s>>>(d_raw, d_out, w, h, tg); break;
+  }
   PT_KCHECK2();
 }
 

@@ -2,6 +2,7 @@
 // pt_shade.h, ...) and the host BVH builder with a plain C++ compiler so that the device
 // LOGIC can be exercised against the oracle on machines without a GPU (and under gdb /
 // host sanitizers).  It is never part of libpt_hip.so and nothing in the product links it.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -10,6 +11,7 @@
 
 #include "../../rust-pathtracer_amd/csrc/bvh_build.h"
 #include "../../rust-pathtracer_amd/csrc/pt_bvh.h"
+#include "../../rust-pathtracer_amd/csrc/pt_demosaic_tile.h"
 #include "../../rust-pathtracer_amd/csrc/pt_shade.h"
 #include "../../rust-pathtracer_amd/csrc/scene.h"
 
@@ -350,3 +352,56 @@ void hc_render(int w, int h, int sample_begin, int sample_count, int max_depth, 
 }
 
 }  // extern "C"
+
+// The interior-tile routine of the gradient demosaic (pt_demosaic_tile.h), tile by tile as the kernel runs it:
+// writes rgb (and covered = 1) for every pixel of a tile whose apron lies inside the image; returns their number.
+namespace {
+template <int P>
+void demosaic_interior_tiles(const float* raw, int w, int h, float* out, unsigned char* covered, long* count) {
+  const dm::TileGrid tg = dm::tile_grid(w, h);
+  std::vector<float> planes(4 * (size_t)dm::kPlane);
+  float* s_raw = planes.data();
+  float* s_g = s_raw + dm::kPlane;
+  float* s_rg = s_g + dm::kPlane;
+  float* s_bg = s_rg + dm::kPlane;
+  for (int by = 1; by < tg.iy1; ++by)
+    for (int bx = 1; bx < tg.ix1; ++bx) {
+      const int x0 = bx * dm::kTileW, y0 = by * dm::kTileH;
+      std::fill(planes.begin(), planes.end(), 0.0f);
+      for (int k = 0; k < dm::kPlane; ++k) {
+        const int yy = k / dm::kStride, xx = k % dm::kStride;
+        s_raw[k] = raw[(size_t)(y0 - dm::kApron + yy) * w + (x0 - dm::kApron + xx)];
+      }
+      for (int q = 0; q < dm::kCellsW * dm::kCellsH; ++q)
+        dm::green_cell<P>(s_raw, s_g, (2 + 2 * (q / dm::kCellsW)) * dm::kStride + 2 + 2 * (q % dm::kCellsW));
+      for (int q = 0; q < dm::kCellsW * dm::kCellsH; ++q)
+        dm::chroma_cell<P>(s_raw, s_g, s_rg, s_bg, (2 + 2 * (q / dm::kCellsW)) * dm::kStride + 2 + 2 * (q % dm::kCellsW));
+      for (int q = 0; q < dm::kOutCellsW * dm::kOutCellsH; ++q) {
+        const int qy = q / dm::kOutCellsW, qx = q % dm::kOutCellsW;
+        float row0[6], row1[6];
+        dm::combine_cell(s_g, s_rg, s_bg, (dm::kApron + 2 * qy) * dm::kStride + dm::kApron + 2 * qx, row0, row1);
+        for (int r = 0; r < 2; ++r) {
+          const size_t i = (size_t)(y0 + 2 * qy + r) * w + (x0 + 2 * qx);
+          memcpy(out + 3 * i, r ? row1 : row0, 6 * sizeof(float));
+          covered[i] = covered[i + 1] = 1;
+          *count += 2;
+        }
+      }
+    }
+}
+}  // namespace
+extern "C" long hc_demosaic_interior(const float* raw, int w, int h, int pattern, float* out, unsigned char* covered) {
+  long count = 0;
+  switch (pattern) {
+    case 0: demosaic_interior_tiles<0>(raw, w, h, out, covered, &count); break;
+    case 1: demosaic_interior_tiles<1>(raw, w, h, out, covered, &count); break;
+    case 2: demosaic_interior_tiles<2>(raw, w, h, out, covered, &count); break;
+    default: demosaic_interior_tiles<3>(raw, w, h, out, covered, &count); break;
+  }
+  return count;
+}
+// the tile grid the kernel launches for a w x h image: tiles across, down, interior bounds, border tiles
+extern "C" void hc_demosaic_tile_grid(int w, int h, int* five) {
+  const dm::TileGrid tg = dm::tile_grid(w, h);
+  five[0] = tg.gw; five[1] = tg.gh; five[2] = tg.ix1; five[3] = tg.iy1; five[4] = tg.n_edge;
+}

@@ -1432,7 +1432,8 @@ def test_adaptive_shared_two_ranks(gpu, tmp_path):
 @pytest.mark.parametrize("algo,name", [(0, "amaze"), (1, "bilinear")])
 def test_demosaic_bit_exact(gpu, oracle, algo, name):
     rng = np.random.default_rng(algo)
-    for shape in [(1, 1), (1, 7), (2, 2), (5, 3), (48, 64), (135, 241)]:
+    # (from 60 x 124 on an image has tiles that lie inside it and take the kernel's other routine)
+    for shape in [(1, 1), (1, 7), (2, 2), (5, 3), (48, 64), (135, 241), (60, 124), (59, 300), (301, 517)]:
         for pattern in range(4):
             raw = rng.uniform(0, 4, shape).astype(np.float32)
             raw[rng.uniform(size=shape) < 0.05] = 0.0

@@ -1300,3 +1300,47 @@ def test_instanced_closed_mesh_does_not_leak(hostcheck):
     finally:
         hostcheck.hc_scene_cornell()
 
+
+
+# ------------------------------------------------------------------ demosaic: the interior-tile routine
+def test_demosaic_interior_tiles_are_the_oracles_bits(hostcheck, oracle):
+    """The gradient demosaic's routine for tiles inside the image (pt_demosaic_tile.h: colours fixed by the pattern,
+    no clamping, the six passes of src/main.rs:190-342 folded into three) against the oracle's pass-by-pass loops,
+    bit for bit, for every pattern; and the tile grid the kernel launches (border tiles listed first, every tile
+    exactly once)."""
+    rng = np.random.default_rng(21)
+    hostcheck.hc_demosaic_interior.restype = C.c_long
+    for (h, w) in [(135, 241), (200, 333), (64, 124), (59, 300), (300, 123)]:
+        five = np.zeros(5, np.int32)
+        hostcheck.hc_demosaic_tile_grid(w, h, P(five, C.c_int))
+        gw, gh, ix1, iy1, n_edge = (int(v) for v in five)
+        assert gw == -(-w // 60) and gh == -(-h // 28)
+        interior = [(bx, by) for by in range(1, iy1) for bx in range(1, ix1)]
+        assert n_edge == gw * gh - len(interior)
+        for bx, by in interior:  # the apron of four lies inside the image
+            assert bx * 60 - 4 >= 0 and by * 28 - 4 >= 0 and bx * 60 + 64 <= w and by * 28 + 32 <= h
+        # no tile that could be interior is left to the border routine for nothing
+        for by in range(gh):
+            for bx in range(gw):
+                fits = bx >= 1 and by >= 1 and bx * 60 + 64 <= w and by * 28 + 32 <= h
+                assert fits == ((bx, by) in interior) or not interior
+        for pattern in range(4):
+            raw = rng.uniform(0, 4, (h, w)).astype(np.float32)
+            raw[rng.uniform(size=(h, w)) < 0.05] = 0.0
+            out = np.full((h, w, 3), -1.0, np.float32)
+            covered = np.zeros((h, w), np.uint8)
+            n = hostcheck.hc_demosaic_interior(P(raw), w, h, pattern, P(out), P(covered, C.c_ubyte))
+            assert n == len(interior) * 60 * 28 == int(covered.sum())
+            want = oracle.demosaic(raw, pattern, "amaze")
+            m = covered.astype(bool)
+            assert np.array_equal(out[m], want[m]), (h, w, pattern)
+            assert (out[~m] == -1.0).all()
+    # a flat field with zeros sprinkled in (gradients of exactly zero, weights of 1e6) keeps its bits too
+    raw = np.full((150, 260), 0.75, np.float32)
+    raw[::7, ::5] = 0.0
+    for pattern in range(4):
+        out = np.zeros((150, 260, 3), np.float32)
+        covered = np.zeros((150, 260), np.uint8)
+        assert hostcheck.hc_demosaic_interior(P(raw), 260, 150, pattern, P(out), P(covered, C.c_ubyte)) > 0
+        m = covered.astype(bool)
+        assert np.array_equal(out[m], oracle.demosaic(raw, pattern, "amaze")[m])
