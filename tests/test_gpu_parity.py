@@ -1442,6 +1442,32 @@ def test_demosaic_bit_exact(gpu, oracle, algo, name):
             assert np.array_equal(got, want), (shape, pattern)
 
 
+def test_demosaic_random_shapes_and_unaligned_buffers(gpu, oracle):
+    """Random image sizes (border tiles only, one interior tile, many; odd and even widths) through the host-buffer
+    entry point, and device buffers that start 4 bytes off an 8-byte boundary through pt_demosaic_device (the
+    interior routine then stores single words instead of pairs): all bit-identical to the oracle's loops."""
+    import torch
+    L = gpu.lib()
+    rng = np.random.default_rng(77)
+    shapes = [(int(rng.integers(1, 200)), int(rng.integers(1, 420))) for _ in range(24)]
+    shapes += [(60, 123), (60, 124), (59, 124), (88, 184), (87, 183), (116, 244)]
+    for k, (h, w) in enumerate(shapes):
+        pattern = k % 4
+        raw = rng.uniform(0, 2, (h, w)).astype(np.float32)
+        raw[rng.uniform(size=(h, w)) < 0.1] = 0.0
+        want = oracle.demosaic(raw, pattern, "amaze")
+        assert np.array_equal(gpu.demosaic(raw, pattern, 0), want), (h, w, pattern)
+        if k % 3 == 0:
+            d_raw = torch.zeros(h * w + 1, dtype=torch.float32, device="cuda:0")
+            d_raw[1:] = torch.from_numpy(raw.ravel()).to("cuda:0")
+            d_out = torch.zeros(h * w * 3 + 1, dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            assert L.pt_demosaic_device(d_raw.data_ptr() + 4, w, h, pattern, 0, d_out.data_ptr() + 4) == 0
+            torch.cuda.synchronize()
+            assert float(d_out[0]) == 0.0
+            assert np.array_equal(d_out[1:].cpu().numpy().reshape(h, w, 3), want), (h, w, pattern, "offset")
+
+
 def test_demosaic_full_size_properties(gpu, oracle):
     """At 3840x2160 (the Bayer configuration's size) the oracle is only run on a crop; the whole
     image is checked through properties: green kept at green sites, non-negative, flat interior."""
