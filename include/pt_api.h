@@ -248,7 +248,9 @@ PT_EXPORT int pt_render_adaptive_shared_device(int w, int h, int sample_begin, i
 PT_EXPORT int pt_mosaic_device(const float* d_rgb, int w, int h, int pattern, float divisor, float* d_raw);
 
 /* Demosaic (src/main.rs:190-415) on the GPU.  algo 0 = gradient method ("AMaZE" in the
- * reference), 1 = bilinear.  Host-pointer and device-pointer forms. */
+ * reference), 1 = bilinear.  Host-pointer and device-pointer forms; the result is the reference's, bit for bit, at
+ * every image size and pattern (a pattern outside 0..3 is clamped, as the reference's cfa_at clamps it).
+ * Returns 0, or -1 for a NULL buffer or an empty image. */
 PT_EXPORT int pt_demosaic_f32(const float* raw, int w, int h, int pattern, int algo, float* out_rgb);
 PT_EXPORT int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, int algo, float* d_out_rgb);
 

@@ -13,8 +13,8 @@
 //   combine_cell green, rg, bg     -> rgb                    (passes 4-6)
 // Terms the reference adds that are +0 here (|0 - 0| between two sites of another colour) are left out: adding +0
 // to a sum of absolute values does not change it.
-// The functions work on plain float arrays, so the kernel runs them on LDS and tests/hostcheck on host memory
-// (both without FMA contraction and with correctly rounded division).
+// The functions work on plain float arrays, so the kernel runs them on LDS and a host build of this header (the
+// CPU test harness, see pt_types.h) on host memory, both without FMA contraction and with correctly rounded division.
 #pragma once
 #include "pt_types.h"
 

@@ -1462,7 +1462,7 @@ int pt_mosaic_device(const float* d_rgb, int w, int h, int pattern, float diviso
 }
 
 int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, int algo, float* d_out_rgb) {
-  if (!d_raw || !d_out_rgb) return -1;
+  if (!d_raw || !d_out_rgb || w <= 0 || h <= 0) return -1;
   HIP_CHECK(hipSetDevice(device_index()));
   const size_t n = (size_t)w * (size_t)h;
   float* tmp = nullptr;
@@ -1496,7 +1496,7 @@ int pt_demosaic_device(const float* d_raw, int w, int h, int pattern, int algo, 
 }
 
 int pt_demosaic_f32(const float* raw, int w, int h, int pattern, int algo, float* out_rgb) {
-  if (!raw || !out_rgb) return -1;
+  if (!raw || !out_rgb || w <= 0 || h <= 0) return -1;
   HIP_CHECK(hipSetDevice(device_index()));
   const size_t n = (size_t)w * (size_t)h;
   float* d_raw = dev_alloc<float>(n);

@@ -540,6 +540,10 @@ def test_png_export_is_the_srgb_encoding_of_the_render(pt, tmp_path):
     assert L.pt_write_png(b"/nonexistent_dir/x.png", 1, 1, P(np.zeros(3, np.float32)), 1.0, 8) == -4
     assert L.pt_write_png(str(tmp_path / "x.png").encode(), 1, 1, P(np.zeros(3, np.float32)), 1.0, 12) == -1
     assert L.pt_write_png(str(tmp_path / "x.png").encode(), 0, 1, P(np.zeros(3, np.float32)), 1.0, 8) == -1
+    # the demosaic entry points turn an empty image or a missing buffer down before anything touches the GPU
+    z = np.zeros(3, np.float32)
+    assert L.pt_demosaic_f32(P(z), 0, 1, 0, 0, P(z)) == -1 and L.pt_demosaic_f32(P(z), 1, -1, 0, 0, P(z)) == -1
+    assert L.pt_demosaic_f32(None, 1, 1, 0, 0, P(z)) == -1 and L.pt_demosaic_device(None, 1, 1, 0, 0, None) == -1
 
 
 def test_exr_reader_rejects_damaged_files(pt, tmp_path):
