@@ -941,6 +941,52 @@ def test_pipelines_agree_and_are_deterministic(gpu):
         L.pt_set_defer_shadow(DEFER_DEFAULT)
 
 
+@pytest.mark.parametrize("spheres,subdiv,tris", [(1, 1, 92), (2, 2, 652), (5, 2, 1612)])
+def test_pipelines_agree_on_trees_of_several_nodes(gpu, spheres, subdiv, tris):
+    """The same agreement on scenes whose tree is more than one node -- spheres in the room: 92 triangles (wide tree
+    in LDS), 652 and 1 612 (packed tree from device memory; the larger one above the size where shadow rays are
+    queued by default) -- where the fused kernels run the general traversal loop: staged kernels, fused launch after
+    launch and fused as one launch give the same bits with shadow rays traced in place, the same image to rounding
+    with the per-wave queue, the same ray counts always, and adaptive renders the same bits and counts."""
+    L = gpu.lib()
+    try:
+        L.pt_scene_synthetic(42, spheres, subdiv)
+        assert gpu.scene_info()["triangles"] == tris
+
+        def render(w, h, spp, **kw):
+            L.pt_set_frame(6)
+            L.pt_reset_ray_counts()
+            img = gpu.render_rgb(w, h, spp, **kw)
+            return img, gpu.ray_counts()
+
+        L.pt_set_pipeline(0)
+        staged, rays = render(320, 180, 32)
+        staged_ad, _ = render(160, 90, 128, noise_threshold=1.5, min_adaptive_samples=32)
+        counts_ad = gpu.sample_counts(160, 90)[0]
+        assert len(np.unique(counts_ad)) > 2
+        L.pt_set_pipeline(1)
+        img, r = render(320, 180, 32)  # the defaults for this scene
+        assert r == rays and np.allclose(img, staged, rtol=2e-5, atol=1e-7)
+        for defer in (0, 1):
+            L.pt_set_defer_shadow(defer)
+            for one_launch in (1, 0):
+                L.pt_set_one_launch(one_launch)
+                img, r = render(320, 180, 32)
+                assert r == rays, (defer, one_launch)
+                if defer == 0:
+                    assert np.array_equal(img, staged), (defer, one_launch)
+                else:
+                    assert np.allclose(img, staged, rtol=2e-5, atol=1e-7), (defer, one_launch)
+                    assert np.array_equal(img, render(320, 180, 32)[0])
+                ad, _ = render(160, 90, 128, noise_threshold=1.5, min_adaptive_samples=32)
+                assert np.array_equal(ad, staged_ad) and np.array_equal(gpu.sample_counts(160, 90)[0], counts_ad), (defer, one_launch)
+    finally:
+        L.pt_set_pipeline(1)
+        L.pt_set_one_launch(1)
+        L.pt_set_defer_shadow(DEFER_DEFAULT)
+        L.pt_scene_cornell()
+
+
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_converged_image_parity(gpu, pipeline):
     """Statistical parity with the high-spp oracle image: relRMSE falls as 1/sqrt(spp) down to the
