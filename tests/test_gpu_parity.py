@@ -980,7 +980,25 @@ def test_pipelines_agree_on_trees_of_several_nodes(gpu, spheres, subdiv, tris):
                     assert np.array_equal(img, render(320, 180, 32)[0])
                 ad, _ = render(160, 90, 128, noise_threshold=1.5, min_adaptive_samples=32)
                 assert np.array_equal(ad, staged_ad) and np.array_equal(gpu.sample_counts(160, 90)[0], counts_ad), (defer, one_launch)
+        # ... and with a guiding field switched on (the guided instantiations of the same kernels)
+        regions, lobes = synthetic_snapshot(seed=77)
+        L.guiding_set_grid_res(4, 4, 4)
+        gpu.upload_snapshot(regions, lobes)
+        L.guiding_set_enabled(1)
+        L.pt_set_one_launch(1)
+        L.pt_set_pipeline(0)
+        guided_staged, guided_rays = render(320, 180, 16)
+        assert guided_rays != rays and not np.array_equal(guided_staged, staged)
+        L.pt_set_pipeline(1)
+        for defer in (0, 1):
+            L.pt_set_defer_shadow(defer)
+            img, r = render(320, 180, 16)
+            assert r == guided_rays
+            assert np.array_equal(img, guided_staged) if defer == 0 else np.allclose(img, guided_staged, rtol=2e-5, atol=1e-7)
     finally:
+        L.guiding_set_enabled(0)
+        L.guiding_set_grid_res(1, 1, 1)
+        gpu.upload_snapshot(np.zeros((0, 8), np.float32), np.zeros((0, 8), np.float32))
         L.pt_set_pipeline(1)
         L.pt_set_one_launch(1)
         L.pt_set_defer_shadow(DEFER_DEFAULT)
