@@ -153,7 +153,8 @@ PT_EXPORT int  pt_get_sample_counts(int* out_counts, int* out_rounds);
  * rays in LDS and traces them 64 at a time, at full occupancy of the wave; a slot's total is the same set of terms
  * added in a different order, so images agree with the staged pipeline to rounding (same paths).  -1 (default):
  * chosen per scene -- queued for trees of more than one node and up to 1024 triangles, where it measures 10 %
- * faster, in place otherwise (the reference's scene: 298 ms in place, 312 ms queued at 1080p, 1024 spp).
+ * faster, unless the scene is small enough (about 90 triangles) to sit in LDS beside the in-place kernel's data;
+ * in place otherwise (the reference's scene: 298 ms in place, 312 ms queued at 1080p, 1024 spp).
  * Adaptive renders always trace in place (the noise test needs per-sample sums). */
 PT_EXPORT void pt_set_defer_shadow(int on);
 PT_EXPORT int  pt_get_defer_shadow(void);

@@ -90,6 +90,7 @@ void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, Que
 // Fused, the whole queue in one launch: every slot of queue qin (length in counters[cnt_in]) runs to its end; lanes take
 // queue entries from counters[CNT_GRAB], which must be zero at the start.  Launch with about as many blocks as stay resident.
 bool bounce_persist_usable(const RenderParams& p);
+bool persist_in_place_stages_scene(const RenderParams& p, int threads);
 void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c);
 
 // Adaptive sampling: active-pixel lists (ping-pong), the 3x3-dilated noise map and each pixel's own noise.

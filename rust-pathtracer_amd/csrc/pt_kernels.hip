@@ -1473,17 +1473,30 @@ static void launch_bounce_t(const RenderParams& p, int qin, int bounces, int com
     else k_bounce<GUIDED, TRAIN, false><<<c.blocks, c.threads, lds, c.stream>>>(p, qin, bounces, compact, cnt);
   }
 }
-static size_t lds_scene_limit() {
-  static const size_t kb = getenv("PT_LDS_SCENE_KB") ? (size_t)atoi(getenv("PT_LDS_SCENE_KB")) : 24u;
-  return kb * 1024u;
+// A scene is staged in LDS when the block still fits four to a CU with it (160 KB of LDS per CU; the kernels are
+// compiled for four waves per SIMD, so a fifth block would find no registers): `other` is what the block needs
+// besides.  PT_LDS_SCENE_KB replaces the rule by a limit on the scene's size alone (experiments).
+constexpr size_t kLdsBlockBudget = 40960;
+static bool scene_goes_to_lds(const RenderParams& p, size_t other, size_t* scene_bytes_out = nullptr) {
+  static const long kb = getenv("PT_LDS_SCENE_KB") ? atol(getenv("PT_LDS_SCENE_KB")) : -1;
+  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
+  if (scene_bytes_out) *scene_bytes_out = scene_bytes;
+  if (!p.scene_in_lds || !p.scene.wide_src) return false;
+  return kb >= 0 ? scene_bytes <= (size_t)kb * 1024u : other + scene_bytes <= kLdsBlockBudget;
+}
+// launch after launch: stacks, camera, and the shadow queues or the slot totals
+static size_t bounce_lds_bytes(const RenderParams& p, int threads, bool& lds_scene) {
+  const bool defer = p.defer_shadow && !p.acc2;
+  const size_t other = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + kCamLdsBytes +
+                       (defer ? (size_t)(threads / 64) * kDeferWords * sizeof(float) : (size_t)threads * kTotalsWords * sizeof(float));
+  size_t scene_bytes;
+  lds_scene = scene_goes_to_lds(p, other, &scene_bytes);
+  return other + (lds_scene ? scene_bytes : 0);
 }
 void launch_bounce(const RenderParams& p, int qin, int bounces, int compact, QueueCounters cnt, const LaunchCfg& c) {
-  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
-  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
-  size_t lds = stack_bytes(p, c) + (lds_scene ? scene_bytes : 0) + kCamLdsBytes;
+  bool lds_scene;
+  const size_t lds = bounce_lds_bytes(p, c.threads, lds_scene);
   const bool defer = p.defer_shadow && !p.acc2;
-  if (defer) lds += (size_t)(c.threads / 64) * kDeferWords * sizeof(float);
-  else lds += (size_t)c.threads * kTotalsWords * sizeof(float);
   const bool g = p.guiding != 0, t = p.train != nullptr;
   if (g && t) launch_bounce_t<true, true>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
   else if (g) launch_bounce_t<true, false>(p, qin, bounces, compact, cnt, c, lds_scene, defer, lds);
@@ -1519,11 +1532,21 @@ static bool persist_defers(const RenderParams& p) {
 // (every render the fused kernels take: kept as the one place to say otherwise)
 bool bounce_persist_usable(const RenderParams&) { return true; }
 static size_t persist_lds_bytes(const RenderParams& p, int threads, bool& lds_scene) {
-  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
-  lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
-  return (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) +
-         (size_t)(threads / 64) * persist_words(persist_defers(p)) * sizeof(float) + kCamLdsBytes +
-         (p.fresh_queue ? 0u : (size_t)(threads / 64) * kStashWords * sizeof(float));
+  const size_t other = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) +
+                       (size_t)(threads / 64) * persist_words(persist_defers(p)) * sizeof(float) + kCamLdsBytes +
+                       (p.fresh_queue ? 0u : (size_t)(threads / 64) * kStashWords * sizeof(float));
+  size_t scene_bytes;
+  lds_scene = scene_goes_to_lds(p, other, &scene_bytes);
+  return other + (lds_scene ? scene_bytes : 0);
+}
+// Would a fixed-count render of this scene by the one-launch kernel, shadow rays traced in place, have the scene in LDS?
+bool persist_in_place_stages_scene(const RenderParams& p, int threads) {
+  RenderParams q = p;
+  q.defer_shadow = 0;
+  q.fresh_queue = 1;
+  bool lds_scene;
+  persist_lds_bytes(q, threads, lds_scene);
+  return lds_scene;
 }
 // The whole of queue qin (its length in counters[cnt_in]) in one launch; counters[CNT_GRAB] must be zero.
 void launch_bounce_persist(const RenderParams& p, int qin, int cnt_in, const LaunchCfg& c) {
@@ -1554,12 +1577,9 @@ int bounce_occupancy(const RenderParams& p, int threads, size_t* lds_out, bool o
                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_persist<false, false, 0, false>, threads, lds);
     return e == hipSuccess ? n : -1;
   }
-  const size_t scene_bytes = 16u * (size_t)staged_scene_words(p.scene_nodes, p.scene.num_items, p.scene.num_tris);
-  const bool lds_scene = p.scene_in_lds && p.scene.wide_src && scene_bytes <= lds_scene_limit();
-  size_t lds = (size_t)threads * (size_t)(p.stack_depth > 0 ? p.stack_depth : 1) * sizeof(StackEntry) + (lds_scene ? scene_bytes : 0) + kCamLdsBytes;
+  bool lds_scene;
+  const size_t lds = bounce_lds_bytes(p, threads, lds_scene);
   const bool defer = p.defer_shadow && !p.acc2;
-  if (defer) lds += (size_t)(threads / 64) * kDeferWords * sizeof(float);
-  else lds += (size_t)threads * kTotalsWords * sizeof(float);
   if (lds_out) *lds_out = lds;
   int n = 0;
   const hipError_t e = defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_defer<false, false, true>, threads, lds)

@@ -500,8 +500,11 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
     // the scene is small enough to stay close: trees of more than one node up to about a thousand triangles
     // (spheres in the room at 1080p, fused kernel, queued against in place: 92 triangles 17.3 against 15.4 Grays/s,
     // 652: 16.9 against 15.4, 1 612: 9.8 against 10.1, 3 212: 9.4 against 9.8; the one-node built-in scene 52.8
-    // against 55.2).
-    p.defer_shadow = g_defer_shadow >= 0 ? g_defer_shadow : ((!s.scene.wide_one_node && s.scene.num_tris <= 1024u) ? 1 : 0);
+    // against 55.2) -- unless the scene fits into LDS beside what the in-place kernel keeps there, which the queues'
+    // 29 KB per block rule out: then in place and from LDS (32 triangles in 5 nodes: 28.3 against 24.8 Grays/s).
+    p.defer_shadow = 0;
+    if (g_defer_shadow >= 0) p.defer_shadow = g_defer_shadow;
+    else if (!s.scene.wide_one_node && s.scene.num_tris <= 1024u && !persist_in_place_stages_scene(p, 256)) p.defer_shadow = 1;
     static const int refill = getenv("PT_REFILL_LANES") ? atoi(getenv("PT_REFILL_LANES")) : 16;
     p.refill_lanes = std::min(std::max(refill, 1), 64);
     static const int shared_env = getenv("PT_SHARED_RANGES") ? atoi(getenv("PT_SHARED_RANGES")) : -1;

@@ -941,11 +941,11 @@ def test_pipelines_agree_and_are_deterministic(gpu):
         L.pt_set_defer_shadow(DEFER_DEFAULT)
 
 
-@pytest.mark.parametrize("spheres,subdiv,tris", [(1, 1, 92), (2, 2, 652), (5, 2, 1612)])
+@pytest.mark.parametrize("spheres,subdiv,tris", [(1, 0, 32), (1, 1, 92), (2, 2, 652), (5, 2, 1612)])
 def test_pipelines_agree_on_trees_of_several_nodes(gpu, spheres, subdiv, tris):
-    """The same agreement on scenes whose tree is more than one node -- spheres in the room: 92 triangles (wide tree
-    in LDS), 652 and 1 612 (packed tree from device memory; the larger one above the size where shadow rays are
-    queued by default) -- where the fused kernels run the general traversal loop: staged kernels, fused launch after
+    """The same agreement on scenes whose tree is more than one node -- spheres in the room: 32 and 92 triangles (wide
+    tree in LDS when shadow rays are traced in place, the default for them), 652 and 1 612 (packed tree from device
+    memory; the larger one above the size where shadow rays are queued by default) -- where the fused kernels run the general traversal loop: staged kernels, fused launch after
     launch and fused as one launch give the same bits with shadow rays traced in place, the same image to rounding
     with the per-wave queue, the same ray counts always, and adaptive renders the same bits and counts."""
     L = gpu.lib()
