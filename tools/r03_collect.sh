@@ -54,7 +54,7 @@ timeout -k 10 200 python3 -u tools/parity_report.py > $OUT/parity_report.json 2>
 timeout -k 10 100 python3 -u tools/occupancy.py > $OUT/occupancy.txt 2>&1
 PT_ADAPTIVE_TRACE=1 timeout -k 10 100 python3 -u tools/adaptive_one.py 1 0.01 > $OUT/adaptive_rounds.txt 2>&1
 rm -f $OUT/small_scenes.txt
-for cfg in "1 1" "2 2" "5 2" "10 2" "20 2" "50 2"; do echo "== scene $cfg" >> $OUT/small_scenes.txt; PIPES=0,1 timeout -k 10 120 python3 -u tools/bigscene_spp.py $cfg 1920 1080 256 2>&1 | grep pipe >> $OUT/small_scenes.txt; done
+for cfg in "1 0" "1 1" "2 2" "5 2" "10 2" "20 2" "50 2"; do echo "== scene $cfg" >> $OUT/small_scenes.txt; PIPES=0,1 timeout -k 10 120 python3 -u tools/bigscene_spp.py $cfg 1920 1080 256 2>&1 | grep pipe >> $OUT/small_scenes.txt; done
 timeout -k 10 900 bash tools/midsize_sweep.sh > $OUT/midsize.txt 2>&1
 timeout -k 10 200 python3 -u tools/config4_full.py > $OUT/config4_full.txt 2>&1
 fi

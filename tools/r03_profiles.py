@@ -60,7 +60,7 @@ bench.py's HIP-event average for the fused kernel in the same run: {r['avg_launc
         open(f"profiles/r03_{name}", "w").write(txt[txt.index("{"):])
     open("profiles/r03_small_and_midsize_scenes.txt", "w").write(
         "# spheres in the room at 1080p, 256 spp (tools/bigscene_spp.py N SUBDIV): staged kernels forced (pipe 0) against the fused kernel (pipe 1).\n"
-        "# Triangles: 1 1 = 92, 2 2 = 652, 5 2 = 1 612, 10 2 = 3 212, 20 2 = 6 412, 50 2 = 16 012; the built-in scene (24 triangles, 12 items in one node) runs at 55 Grays/s\n"
+        "# Triangles: 1 0 = 32 (five nodes; in LDS, shadow rays in place), 1 1 = 92 (in LDS, in place), 2 2 = 652, 5 2 = 1 612, 10 2 = 3 212, 20 2 = 6 412, 50 2 = 16 012; the built-in scene (24 triangles, 12 items in one node) runs at 55 Grays/s\n"
         + rd("small_scenes.txt") + "\n# larger scenes under the default choice (tools/midsize_sweep.sh)\n" + rd("midsize.txt"))
     open("profiles/r03_occupancy_and_adaptive_rounds.txt", "w").write(
         "# resident blocks per CU and LDS per block of the fused kernels (tools/occupancy.py)\n" + rd("occupancy.txt")
