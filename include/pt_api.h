@@ -289,7 +289,8 @@ PT_EXPORT int pt_dbg_fused_occupancy(int adaptive, unsigned long long* lds_bytes
 PT_EXPORT double pt_last_render_ms(void);
 /* Chunks the last render split every pixel's sample range into (each chunk is a path slot with a random stream of
  * its own, all in flight together).  Fixed-count renders of scenes that run fused: min(16, 33554432 / (w*h)), lowered
- * until every chunk has 32 samples.  Scenes that run staged by default (trees beyond 256 KiB, instances) keep more
+ * until every chunk has 32 samples, the last of them then cut into up to four shorter ones (so 19 for 16: the render
+ * ends on short slots; env PT_TAIL_SPLIT=0 keeps them equal).  Scenes that run staged by default (trees beyond 256 KiB, instances) keep more
  * in flight: min(64, 150994944 / (w*h)) chunks of as little as one sample, path state of 164 bytes per slot
  * growing on demand up to a quarter of the free device memory.  strict_parity: 1. */
 PT_EXPORT int pt_last_render_chunks(void);

@@ -22,7 +22,8 @@ struct RenderParams {
   int sample_begin, sample_count;  // this call renders global samples [begin, begin+count) per pixel
   uint32_t npx;                    // width * height
   uint32_t npx_inv, width_inv;     // ceil(2^32 / npx), ceil(2^32 / width): division by multiplication (decode_slot)
-  int chunks, chunk_spp;           // the range is split into `chunks` slots per pixel of chunk_spp samples
+  int chunks, chunk_spp;           // the range is split into `chunks` slots per pixel: the first chunk_long of them
+  int chunk_long, chunk_short;     // chunk_spp samples long, the rest chunk_short (decode_slot)
   int round_limit;                 // > 0: no slot goes beyond this many samples yet (adaptive rounds)
   int strict;                      // 1: replay the reference's 4-sample launches literally
   int guiding;

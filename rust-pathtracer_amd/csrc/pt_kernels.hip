@@ -105,9 +105,12 @@ __device__ __forceinline__ Slot decode_slot(const RenderParams& p, uint32_t slot
   s.pixel = slot - chunk * p.npx;
   s.y = (int)fast_div(s.pixel, (uint32_t)p.width, p.width_inv);
   s.x = (int)(s.pixel - (uint32_t)s.y * (uint32_t)p.width);
-  s.begin = p.sample_begin + (int)chunk * p.chunk_spp;
-  const int rem = p.sample_count - (int)chunk * p.chunk_spp;
-  s.count = rem < p.chunk_spp ? (rem > 0 ? rem : 0) : p.chunk_spp;
+  const int c = (int)chunk, is_long = c < p.chunk_long;
+  const int first = is_long ? c * p.chunk_spp : p.chunk_long * p.chunk_spp + (c - p.chunk_long) * p.chunk_short;
+  const int len = is_long ? p.chunk_spp : p.chunk_short;
+  s.begin = p.sample_begin + first;
+  const int rem = p.sample_count - first;
+  s.count = rem < len ? (rem > 0 ? rem : 0) : len;
   if (p.round_limit > 0 && s.count > p.round_limit) s.count = p.round_limit;
   return s;
 }
@@ -1050,6 +1053,11 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   uint32_t head = 0, waiting = 0, queued_total = 0, traced_total = 0;  // the LDS queue
   uint32_t grab_pos = 0, grab_end = 0, grab_base = 0;                   // the stretch of the slot queue the wave holds
   bool more = n > 0u;                                                   // the shared counter has not run past the queue yet
+#ifdef PT_PROFILE
+  // when the first wave starts, when the first and the last wave find the queue empty, when the last wave ends
+  // (100 MHz clock; minima kept as maxima of 2^62 - t): words 56..59 of the counters
+  if (lane == 0u) atomicMax(&g_prof_global[56], (1ull << 62) - (unsigned long long)wall_clock64());
+#endif
   PT_TIC(t_loop);
   for (;;) {
     // a slot whose last sample is folded and whose queued rays are all traced goes back to memory
@@ -1086,7 +1094,17 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
           uint32_t b = 0u;
           if (lane == 0u) b = atomicAdd(&p.counters[CNT_GRAB], grab);
           b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-          if (b >= n) { more = false; break; }
+          if (b >= n) {
+#ifdef PT_PROFILE
+            if (lane == 0u) {
+              const unsigned long long t = (unsigned long long)wall_clock64();
+              atomicMax(&g_prof_global[57], (1ull << 62) - t);
+              atomicMax(&g_prof_global[58], t);
+            }
+#endif
+            more = false;
+            break;
+          }
           grab_pos = grab_base = b;
           grab_end = b + grab < n ? b + grab : n;
           if (!fresh) {
@@ -1217,6 +1235,7 @@ __global__ void __launch_bounds__(256, PT_BOUNCE_WAVES) k_bounce_persist(RenderP
   }
   PT_TOC(t_loop, PT_T_LOOP);
 #ifdef PT_PROFILE
+  if (lane == 0u) atomicMax(&g_prof_global[59], (unsigned long long)wall_clock64());
   __syncthreads();
   if (threadIdx.x < 64 && g_prof_lds[threadIdx.x]) atomicAdd(&g_prof_global[threadIdx.x], (unsigned long long)g_prof_lds[threadIdx.x]);
 #endif

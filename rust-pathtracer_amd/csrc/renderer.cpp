@@ -366,10 +366,48 @@ int planned_chunks(size_t px, int sample_count, bool staged_scene) {
   while (chunks > 1 && sample_count / chunks < min_chunk) --chunks;
   return chunks;
 }
-int chunks_for_render(State& s, int sample_count, bool strict) {
-  if (strict) return 1;
+// How a pixel's sample range is cut into slots: long_n chunks of long_len samples, then chunks of short_len.
+struct ChunkPlan {
+  int chunks, long_n, long_len, short_len;
+};
+ChunkPlan uniform_plan(int sample_count, int n) {
+  n = std::max(n, 1);
+  const int len = (sample_count + n - 1) / n;
+  return ChunkPlan{n, n, len, len};
+}
+// A fixed-count render of a scene that runs fused ends with short slots: the one-launch kernel is over when the last
+// lane has finished the slot it holds, and from the moment the queue is empty the GPU runs emptier and emptier for
+// as long as the longest slots take (1080p, section clock of the profiling build: 9.5 ms of 369 with 64-sample slots
+// everywhere, 5 ms with 32-sample slots, 1.5 ms with 8-sample slots -- which cost as much again in slot changes when
+// every slot is that short).  So the last of the n chunks is cut into PT_TAIL_SPLIT (4) short ones, which the queue,
+// chunk after chunk, lists last.
+ChunkPlan layout_from(int sample_count, int n, bool split_tail) {
+  static const int split = getenv("PT_TAIL_SPLIT") ? atoi(getenv("PT_TAIL_SPLIT")) : 4;
+  const ChunkPlan u = uniform_plan(sample_count, n);
+  if (!split_tail || n < 2 || split < 2) return u;
+  const int rem = sample_count - (n - 1) * u.long_len;  // what the last chunk holds
+  const int short_len = std::max((rem + split - 1) / split, 4);
+  const int n_short = rem > 0 ? (rem + short_len - 1) / short_len : 0;
+  if (n_short < 2) return u;
+  return ChunkPlan{n - 1 + n_short, n - 1, u.long_len, short_len};
+}
+ChunkPlan planned_layout(size_t px, int sample_count, bool staged_scene) {
+  return layout_from(sample_count, planned_chunks(px, sample_count, staged_scene), !staged_scene);
+}
+ChunkPlan plan_for_render(State& s, int sample_count, bool strict) {
+  if (strict) return uniform_plan(sample_count, 1);
   const size_t px = (size_t)s.width * (size_t)s.height;
-  return fit_chunks(s, planned_chunks(px, sample_count, !s.borrowed && staged_by_default(s)));
+  const bool staged_scene = !s.borrowed && staged_by_default(s);
+  const int n = planned_chunks(px, sample_count, staged_scene);
+  if (s.borrowed) {  // arrays of a fixed size: the plan of the same render with arrays that grow, as far as it fits
+    const int n_fit = std::min(n, s.max_chunks);
+    const ChunkPlan want = layout_from(sample_count, n_fit, true);
+    return want.chunks <= s.max_chunks_split ? want : uniform_plan(sample_count, n_fit);
+  }
+  const ChunkPlan want = layout_from(sample_count, n, !staged_scene);
+  const int got = fit_chunks(s, want.chunks);
+  if (got == want.chunks) return want;
+  return uniform_plan(sample_count, std::min(got, n));  // less room than that
 }
 
 // optix_wrapper.cpp:784-920
@@ -487,9 +525,12 @@ RenderParams make_params(State& s, int sample_begin, int sample_count, int max_d
   auto inv32 = [](uint32_t b) { return b > 1u ? (uint32_t)(((1ull << 32) + b - 1u) / b) : 0u; };  // 0: divide by one
   p.npx_inv = inv32(p.npx);
   p.width_inv = inv32((uint32_t)s.width);
-  // chunks: strict mode replays one stream per pixel; converge mode splits the range (chunks_for_render)
-  p.chunks = std::max(grow ? chunks_for_render(s, sample_count, strict) : 1, 1);
-  p.chunk_spp = (sample_count + p.chunks - 1) / p.chunks;
+  // chunks: strict mode replays one stream per pixel; converge mode splits the range (plan_for_render)
+  const ChunkPlan plan = grow ? plan_for_render(s, sample_count, strict) : uniform_plan(sample_count, 1);
+  p.chunks = plan.chunks;
+  p.chunk_spp = plan.long_len;
+  p.chunk_long = plan.long_n;
+  p.chunk_short = plan.short_len;
   p.guiding = (g_guiding_enabled && s.guide_valid) ? 1 : 0;
   p.stack_depth = s.bvh_depth;
   p.scene_nodes = (uint32_t)s.num_nodes;
@@ -771,6 +812,8 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
   RenderParams p = make_params(s, sample_begin, spp, max_depth, frame, strict, false);  // after the arrays may have grown
   p.chunks = chunks;
   p.chunk_spp = (spp + chunks - 1) / chunks;
+  p.chunk_long = chunks;  // chunks of one length: the rounds divide by them
+  p.chunk_short = p.chunk_spp;
   p.acc2 = s.acc2;
   RenderLoop loop(s, p);
   s.last_chunks = chunks;
@@ -923,7 +966,7 @@ void render_mean_sharded(State& s, int n, int spp, int max_depth, float noise_th
       HIP_CHECK(hipMemsetAsync(sd->d_shard_stats, 0, (size_t)npx * 8 * sizeof(float), sd->stream));
     } else {
       const int begin = (int)((long long)d * spp / n), count = (int)((long long)(d + 1) * spp / n) - begin;
-      const int want = planned_chunks(npx, count, staged_by_default(*sd));
+      const int want = planned_layout(npx, count, staged_by_default(*sd)).chunks;
       fit_chunks(*sd, std::max(1, want / on_device[(size_t)d]));  // its part of what the GPU has room for
     }
   }
@@ -1412,6 +1455,7 @@ int pt_render_accumulate_device_noalloc(int w, int h, int sample_begin, int samp
   s.width = w;
   s.height = h;
   s.max_chunks = s.base_chunks = max_chunks_for(px);  // the same split into chunks as pt_render_accumulate_device ...
+  s.max_chunks_split = (int)std::max<size_t>(1, std::min<size_t>((size_t)s.max_chunks + 3, kNaMaxSlots / std::max<size_t>(px, 1)));
   const float eye[3] = {0.f, 3.f, 1.f}, look[3] = {0.f, 0.f, 1.f}, up[3] = {0.f, 0.f, 1.f};
   set_camera(s, eye, look, up, 45.f);
   RenderParams p = make_params(s, sample_begin, sample_count, max_depth, frame, false);

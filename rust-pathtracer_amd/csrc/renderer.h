@@ -39,6 +39,7 @@ struct State {
   int width = 0, height = 0;
   int num_cus = 256;
   int max_chunks = 1;   // slots allocated per pixel (grows when a render of a large scene wants more)
+  int max_chunks_split = 1;  // arrays of a fixed size (borrowed): slots per pixel a plan with a cut last chunk may take
   int base_chunks = 1;  // what a renderer of this resolution starts with: the limit for adaptive renders
   int last_chunks = 1;  // chunks used by the most recent render
   hipStream_t stream = nullptr, copy_stream = nullptr;
