@@ -211,7 +211,7 @@ PT_EXPORT int pt_render_accumulate_device(int w, int h, int sample_begin, int sa
  * library is loaded on until the process ends), and the call makes no hipMalloc / hipFree / hipHostMalloc /
  * stream or event creation: work runs on the null stream, the live-slot counter is read back with a blocking
  * copy after every batch of launches.  Limits: w * h * chunks <= PT_NOALLOC_MAX_SLOTS, where chunks is what
- * pt_render_accumulate_device would use (min(16, 33554432 / (w*h)), lowered until every chunk has 32 samples, so
+ * pt_render_accumulate_device would use (min(8, 33554432 / (w*h)), lowered until every chunk has 32 samples, the last one cut into up to four, so
  * 1 for sample_count < 64); the scene's BVH nodes, leaf items and shading records together at most
  * PT_NOALLOC_MAX_SCENE_BYTES (the built-in scene: 3.6 KB); guiding off.  Returns 0, -1 for a NULL output, -2
  * with the reason on stderr when a limit is exceeded (nothing is rendered then).  Every call on a GPU uses
@@ -288,8 +288,8 @@ PT_EXPORT int pt_dbg_fused_occupancy(int adaptive, unsigned long long* lds_bytes
 /* Wall time of the device work of the last render call (HIP events around the whole loop). */
 PT_EXPORT double pt_last_render_ms(void);
 /* Chunks the last render split every pixel's sample range into (each chunk is a path slot with a random stream of
- * its own, all in flight together).  Fixed-count renders of scenes that run fused: min(16, 33554432 / (w*h)), lowered
- * until every chunk has 32 samples, the last of them then cut into up to four shorter ones (so 19 for 16: the render
+ * its own, all in flight together).  Fixed-count renders of scenes that run fused: min(8, 33554432 / (w*h)), lowered
+ * until every chunk has 32 samples, the last of them then cut into up to four shorter ones (so 11 for 8: the render
  * ends on short slots; env PT_TAIL_SPLIT=0 keeps them equal).  Scenes that run staged by default (trees beyond 256 KiB, instances) keep more
  * in flight: min(64, 150994944 / (w*h)) chunks of as little as one sample, path state of 164 bytes per slot
  * growing on demand up to a quarter of the free device memory.  strict_parity: 1. */

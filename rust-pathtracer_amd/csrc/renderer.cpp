@@ -346,9 +346,12 @@ int fit_chunks(State& s, int chunks) {
 constexpr size_t kFusedTreeBytes = (size_t)256u << 10;
 bool staged_by_default(const State& s) { return s.scene.inst_records != nullptr || s.bvh_bytes > kFusedTreeBytes; }
 
-// Chunks (slots per pixel) of a fixed-count render.  Scenes that run fused keep up to 32 M slots in flight in up to
-// 16 chunks of at least 32 samples (1080p, 1024 spp, with the queue compacted by every launch: 8 M slots 404.7 ms,
-// 16 M 395.7, 32 M 390.2: the more slots, the later the launches run out of full waves).  Scenes that run staged (larger trees, instances) do better the more of
+// Chunks (slots per pixel) of a fixed-count render.  Scenes that run fused: up to 8 chunks of at least 32 samples (the
+// last one then cut into short ones, planned_layout).  With the launch-after-launch kernel more slots were better
+// (1080p, 1024 spp, queue compacted by every launch: 8 M slots 404.7 ms, 16 M 395.7, 32 M 390.2: the more slots, the
+// later the launches run out of full waves); the one-launch kernel only cares how long a slot is -- every change of
+// slot costs a lane a few dozen instructions, the end of the render is taken care of by the short final slots --
+// and runs 8 chunks of 128 samples 0.5 % faster than 16 of 64 (297.5 against 299.4 ms; 4 of 256 the same).  Scenes that run staged (larger trees, instances) do better the more of
 // their samples are in flight at once -- every launch is one bounce of every live path, so fewer, larger launches
 // leave fewer half-empty waves behind: up to 64 chunks of as little as one sample, 144 M slots (22 GB of the
 // GPU's 288) at most and never more than a quarter of what is free.  The state arrays grow when a render needs it.
@@ -358,7 +361,7 @@ int planned_chunks(size_t px, int sample_count, bool staged_scene) {
   static const int min_chunk_env = getenv("PT_MIN_CHUNK_SAMPLES") ? std::max(atoi(getenv("PT_MIN_CHUNK_SAMPLES")), 1) : 0;
   px = std::max<size_t>(px, 1);
   static const int most_env = getenv("PT_MAX_CHUNKS") ? atoi(getenv("PT_MAX_CHUNKS")) : 0;
-  const int most = most_env > 0 ? most_env : (staged_scene ? 64 : 16);
+  const int most = most_env > 0 ? most_env : (staged_scene ? 64 : 8);
   const size_t target = target_env ? target_env : (staged_scene ? (size_t)144 << 20 : kFusedTargetSlots);
   const int min_chunk = min_chunk_env ? min_chunk_env : (staged_scene ? 1 : 32);
   int chunks = (int)std::max<size_t>(1, std::min<size_t>((size_t)most, target / px));
@@ -1625,7 +1628,10 @@ int pt_last_render_chunks(void) { return g_handle ? g_handle->last_chunks : 0; }
 int pt_dbg_chunk_plan(int w, int h, int sample_count, int staged_scene, int have_chunks, unsigned long long free_bytes) {
   if (w <= 0 || h <= 0 || sample_count < 0 || have_chunks < 1) return -1;
   const size_t px = (size_t)w * (size_t)h;
-  return chunks_that_fit(px, planned_chunks(px, sample_count, staged_scene != 0), have_chunks, (size_t)free_bytes);
+  const int n = planned_chunks(px, sample_count, staged_scene != 0);
+  const int want = planned_layout(px, sample_count, staged_scene != 0).chunks;  // with the last chunk cut (plan_for_render)
+  const int got = chunks_that_fit(px, want, have_chunks, (size_t)free_bytes);
+  return got == want ? want : std::min(got, n);
 }
 
 void pt_scene_cornell(void) {

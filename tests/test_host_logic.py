@@ -628,18 +628,20 @@ def test_later_sample_ranges_start_streams_that_differ_between_pixels(hostcheck)
 
 
 def test_chunk_plan(pt):
-    """Slots per pixel of a fixed-count render.  Scenes that run fused: 32 Mi slots, chunks of 32 samples and more, 16
-    at most.  Scenes that run staged: 144 Mi slots, chunks of one sample and more, 64 at most.  The renderer grows
-    to that if a quarter of the free memory (its own 164 bytes per slot counted as free) holds it, else to what
-    does, and never shrinks."""
+    """Slots per pixel of a fixed-count render.  Scenes that run fused: 32 Mi slots, chunks of 32 samples and more, 8
+    at most, the last of them cut into four (of at least 4 samples) so that the render ends on short slots.  Scenes
+    that run staged: 144 Mi slots, chunks of one sample and more, 64 at most.  The renderer grows to that if a
+    quarter of the free memory (its own 164 bytes per slot counted as free) holds it, else to what does, and never
+    shrinks."""
     plan = pt.lib().pt_dbg_chunk_plan
     big = 1 << 40
     # fused scenes
-    assert plan(1920, 1080, 1024, 0, 1, big) == 16      # 32 Mi / 2 Mi pixels
-    assert plan(1920, 1080, 100, 0, 1, big) == 3        # 100 // 3 = 33 >= 32 samples each
+    assert plan(1920, 1080, 1024, 0, 1, big) == 7 + 4   # 7 chunks of 128 samples and 4 of 32
+    assert plan(1920, 1080, 100, 0, 1, big) == 2 + 4    # 100 // 3 = 33 >= 32: 2 chunks of 34 samples and 4 of 8
     assert plan(1920, 1080, 63, 0, 1, big) == 1
-    assert plan(3840, 2160, 4096, 0, 1, big) == 4       # 32 Mi / 8.3 M pixels
-    assert plan(64, 36, 4096, 0, 1, big) == 16
+    assert plan(3840, 2160, 4096, 0, 1, big) == 3 + 4   # 32 Mi / 8.3 M pixels = 4 chunks, the last cut
+    assert plan(64, 36, 4096, 0, 1, big) == 7 + 4
+    assert plan(1920, 1080, 1024, 0, 8, 0) == 8         # no room for the cut: eight equal chunks
     # staged scenes
     assert plan(1920, 1080, 256, 1, 1, big) == 64
     assert plan(3840, 2160, 16, 1, 1, big) == 16
