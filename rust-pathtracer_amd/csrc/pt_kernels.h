@@ -24,7 +24,8 @@ struct RenderParams {
   uint32_t npx_inv, width_inv;     // ceil(2^32 / npx), ceil(2^32 / width): division by multiplication (decode_slot)
   int chunks, chunk_spp;           // the range is split into `chunks` slots per pixel: the first chunk_long of them
   int chunk_long, chunk_short;     // chunk_spp samples long, the rest chunk_short (decode_slot)
-  int round_limit;                 // > 0: no slot goes beyond this many samples yet (adaptive rounds)
+  int round_limit;                 // > 0: no slot goes beyond this many samples yet (adaptive rounds);
+  int round_limit_b, round_split;  // ... chunks from round_split on: round_limit_b (the last chunk's smaller share)
   int strict;                      // 1: replay the reference's 4-sample launches literally
   int guiding;
   int stack_depth;                 // traversal stack entries per lane

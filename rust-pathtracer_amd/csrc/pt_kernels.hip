@@ -111,7 +111,10 @@ __device__ __forceinline__ Slot decode_slot(const RenderParams& p, uint32_t slot
   s.begin = p.sample_begin + first;
   const int rem = p.sample_count - first;
   s.count = rem < len ? (rem > 0 ? rem : 0) : len;
-  if (p.round_limit > 0 && s.count > p.round_limit) s.count = p.round_limit;
+  if (p.round_limit > 0) {
+    const int limit = c < p.round_split ? p.round_limit : p.round_limit_b;
+    if (s.count > limit) s.count = limit;
+  }
   return s;
 }
 // Sample index fed to the jitter hash, and the PCG state the sample starts from.
