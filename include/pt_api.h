@@ -140,8 +140,8 @@ PT_EXPORT void pt_set_adaptive_round(int samples);
 PT_EXPORT int  pt_get_adaptive_round(void);
 /* Adaptive renders split a pixel's samples into several chunks rendered side by side (own random stream
  * each, like the ranks of a sharded render) where that keeps enough paths in flight; every chunk takes the
- * same number of samples per round (one rank, scenes that run fused: the last chunk about a quarter of the others'
- * part of a long round, so that a round ends on short slots).  0 (default): as many as 16 M slots allow (8 at 1920x1080), a power of two that
+ * same number of samples per round (scenes that run fused: the last chunk about a quarter of the others' part of a
+ * long round, so that a round ends on short slots; the shared-statistics entry point follows the same schedule).  0 (default): as many as 16 M slots allow (8 at 1920x1080), a power of two that
  * divides the round and leaves every chunk at least 4 samples of it (scenes that run staged by default: up to 64,
  * at least 1 sample; see pt_last_render_chunks); 1: one stream per pixel, the sample sequence of the reference's
  * launch loop.  Env: PT_ADAPTIVE_CHUNKS. */

@@ -817,23 +817,23 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
   p.chunk_spp = (spp + chunks - 1) / chunks;
   p.chunk_long = chunks;  // chunks of one length: the rounds divide by them
   p.chunk_short = p.chunk_spp;
-  // Scenes that run fused, one rank: the last chunk takes a smaller part of every long round (about a third of what
+  // Scenes that run fused: the last chunk takes a smaller part of every long round (about a third of what
   // the others take).  A round is one launch over the active pixels' slots, chunk after chunk, and it is over when
   // the last lane has finished the slot it holds: with the last chunk's slots short, the GPU runs empty for a
   // third as long at the end of every round.  The parts are fixed before the first round (the schedule of rounds
   // does not depend on what the noise test finds): per round and chunk how many samples, and so every chunk's
   // range of the pixel's samples.
   std::vector<int> part_a, part_b;  // cumulative samples after each round: the first chunks - 1 chunks, the last one
-  if (!strict && !shared && chunks >= 4 && !(!s.borrowed && staged_by_default(s))) {
+  if (!strict && chunks >= 4 && !(!s.borrowed && staged_by_default(s))) {
     static const int uneven_from = getenv("PT_ADAPTIVE_UNEVEN") ? atoi(getenv("PT_ADAPTIVE_UNEVEN")) : 16;
-    int d = 0, a_sum = 0, b_sum = 0;
+    int d = 0, d_mine = 0, a_sum = 0, b_sum = 0;
     bool ok = uneven_from > 0;
-    while (ok && d < total) {
+    while (ok && d < total) {  // the rounds of the loop below, this rank's share of each
       int t = next_target(d);
       while (t < min_samples && t < total) t = next_target(t);
       t = std::min(t, total);
-      const int quota = t - d;
-      if (quota % chunks != 0) { ok = false; break; }
+      const int mine = local_target(t), quota = mine - d_mine;
+      if (quota < 0 || quota % chunks != 0) { ok = false; break; }
       int a = quota / chunks, b = a;
       if (a >= uneven_from) {
         a = (int)((4LL * quota) / (4LL * chunks - 3));  // chunks - 1 parts of a and one of about a / 4 (2, 8, 16: slower) ...
@@ -842,6 +842,7 @@ int render_adaptive(State& s, int sample_begin, int spp, int max_depth, int fram
       a_sum += a; b_sum += b;
       part_a.push_back(a_sum); part_b.push_back(b_sum);
       d = t;
+      d_mine = mine;
     }
     if (ok && !part_a.empty() && (chunks - 1) * a_sum + b_sum == spp && b_sum > 0 && a_sum != b_sum) {
       p.chunk_spp = a_sum;

@@ -1373,6 +1373,13 @@ def test_adaptive_shared_one_rank_is_plain_adaptive(gpu):
     c = counts.cpu().numpy()
     assert set(np.unique(c)) <= {32.0, 64.0, 128.0} and len(np.unique(c)) > 1
     assert len(calls) == 3  # after 32 and 64 samples, and the totals at the end
+    # a longer render, whose later rounds give the last chunk its smaller part: still the same bits from both
+    big, big_n = torch.zeros_like(sums), torch.zeros_like(counts)
+    torch.cuda.synchronize()
+    gpu.render_adaptive_accumulate_device(big, big_n, w, h, 0, 512, 32, 5, thr, 32)
+    torch.cuda.synchronize()
+    gpu.render_adaptive_shared_device(stats, w, h, 0, 512, 512, 32, 5, thr, 32, reduce=None)
+    assert torch.equal(v[:, 0:3].reshape(-1), big) and torch.equal(v[:, 3], big_n) and float(big_n.max()) == 512.0
     # NULL reduce and the helper give the same
     renderer = sharded.DeviceSharedAdaptiveRenderer(w, h, 32, 5, thr, 32, dev)
     mean, cnt = sharded.render_sharded_adaptive_shared(renderer, w, h, 0, spp, spp, device=dev)
